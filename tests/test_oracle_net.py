@@ -1,0 +1,111 @@
+"""Pins oracle/rdm_net_cpu.py (conv stack, DORN head, tail, training step, gradients)
+against fixtures produced by RUNNING the reference (tests/golden/net_goldens.npz). CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from md_rdm_amd import filler
+from oracle import rdm_net_cpu as onet
+from conftest import GOLDEN
+
+TAPS = ["conv_e1", "max_e1", "dense_e2", "trans_e2", "dense_e3", "trans_e3", "dense_e4", "trans_e4", "d1_dense", "d1_conv2"]
+
+
+def test_state_dict_keys_match_reference():
+    want = [l.split(" ", 1) for l in open(os.path.join(GOLDEN, "state_dict_keys.txt")).read().splitlines()]
+    spec = onet.state_dict_spec()
+    assert len(spec) == 968 == len(want)
+    for (k, shape, dt), (wk, rest) in zip(spec, want):
+        assert k == wk
+        assert rest == f"{tuple(shape)} {dt}"
+    n = sum(int(np.prod(s)) for k, s, dt in spec if dt == "float32" and "running" not in k)
+    assert n == 90529721
+
+
+@pytest.fixture(scope="module")
+def train_run():
+    torch.set_num_threads(8)
+    sd = onet.new_state_dict(filler.state_value)
+    x, y = filler.synthetic_batch(2, 228, 228, seed=1234)
+    out = onet.training_step(sd, torch.from_numpy(x), y)
+    return sd, out
+
+
+def test_train_step_forward(net_gold, train_run):
+    sd, out = train_run
+    np.testing.assert_allclose(out["logits"], net_gold["train228_logits"], rtol=0, atol=2e-4 * np.abs(net_gold["train228_logits"]).max())
+    # ordinal indices: bit-exact wherever the reference's own margin exceeds the conv noise
+    lg = net_gold["train228_logits"]
+    margin = np.abs(np.clip(lg[:, 1::2], 1e-8, 1e4) - np.clip(lg[:, 0::2], 1e-8, 1e4))
+    risky = ((margin > 0) & (margin < 1e-3)).sum(1, keepdims=True)
+    safe = risky == 0
+    assert safe.mean() > 0.5
+    np.testing.assert_array_equal(out["decode"][safe], net_gold["train228_decode_c"][safe])
+    assert np.abs(out["decode"] - net_gold["train228_decode_c"]).max() <= risky.max()
+    np.testing.assert_allclose(out["P"], net_gold["train228_ord_labels"], atol=2e-4)
+    np.testing.assert_array_equal(out["ord_y"], net_gold["train228_ord_y"])
+    if np.array_equal(out["decode"], net_gold["train228_decode_c"]):
+        for i in range(4):
+            np.testing.assert_allclose(out["y_hat"][i], net_gold[f"train228_yhat{i}"], rtol=1e-4, atol=5e-6)  # atol: log-domain values near log(1)=0 inherit the f32 gm rounding of the reference
+    np.testing.assert_allclose(out["target_components"][0], net_gold["train228_target_comp0"], rtol=5e-6)  # reference f32 gm chain
+    np.testing.assert_allclose(out["target_components"][3], net_gold["train228_target_comp3"], rtol=1e-9)
+    want = net_gold["train228_losses"]
+    got = np.array([out["mse"], out["fine_detail_loss"], out["ord_loss"], out["loss_all"]])
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    np.testing.assert_allclose(out["final_depth"][:, :, :4, :4], net_gold["train228_final_depth_corner"], rtol=1e-4, atol=1e-6)
+
+
+def test_train_step_gradients(net_gold, train_run):
+    sd, out = train_run
+    names = [str(n) for n in net_gold["train228_grad_names"]]
+    gn = net_gold["train228_grad_norm"]
+    for name, want in zip(names, gn):
+        g = out["grads"][name]
+        if want < 0:
+            assert g is None or float(g.abs().max()) == 0.0, name
+        else:
+            assert abs(float(g.double().norm()) - want) <= 2e-3 * want + 1e-9, (name, float(g.double().norm()), want)
+    for k in net_gold.files:
+        if k.startswith("train228_grad__"):
+            name = k[len("train228_grad__"):]
+            ref = net_gold[k]
+            np.testing.assert_allclose(out["grads"][name].numpy(), ref, rtol=0, atol=2e-3 * np.abs(ref).max() + 1e-9)
+
+
+def test_running_stats_after_one_step(net_gold, train_run):
+    sd, _ = train_run
+    for k in net_gold.files:
+        if k.startswith("train228_rm__"):
+            n = k[len("train228_rm__"):]
+            np.testing.assert_allclose(sd[n + ".running_mean"].numpy(), net_gold[k], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(sd[n + ".running_var"].numpy(), net_gold["train228_rv__" + n], rtol=1e-4)
+            assert int(sd[n + ".num_batches_tracked"]) == int(net_gold["train228_nbt__" + n]) == 1
+
+
+def test_eval_forward_226(net_gold):
+    sd = onet.new_state_dict(filler.state_value)
+    x, _ = filler.synthetic_batch(1, 226, 226, seed=77)
+    taps = {}
+    y_hat, decode, P, logits = onet.forward(sd, torch.from_numpy(x), training=False, taps=taps)
+    for t in TAPS:
+        np.testing.assert_allclose(taps[t], net_gold[f"eval226_tap_{t}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(logits, net_gold["eval226_logits"], atol=2e-4 * np.abs(net_gold["eval226_logits"]).max())
+    np.testing.assert_allclose(P, net_gold["eval226_ord_labels"], atol=2e-4)
+    if np.array_equal(decode, net_gold["eval226_decode_c"]):
+        for i in range(4):
+            np.testing.assert_allclose(y_hat[i], net_gold[f"eval226_yhat{i}"], rtol=1e-4, atol=5e-6)
+
+
+def test_rectangular_head_228x304(net_gold):
+    sd = onet.new_state_dict(filler.state_value)
+    x, _ = filler.synthetic_batch(2, 228, 304, seed=1234)
+    taps = {}
+    y_hat, decode, P, logits = onet.forward(sd, torch.from_numpy(x), training=True, taps=taps)
+    assert decode.shape == (2, 1, 8, 10) and P.shape == (2, 90, 8, 10)
+    for t in TAPS:
+        np.testing.assert_allclose(taps[t], net_gold[f"train228x304_tap_{t}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(P, net_gold["train228x304_ord_labels"], atol=2e-4)
+    assert int(net_gold["train228x304_full_forward_raises"]) == 1      # the reference itself stops here
+    assert [t.shape for t in y_hat] == [(2, 1, 1, 1), (2, 1, 2, 2), (2, 1, 4, 4), (2, 1, 8, 8)]  # documented generalisation
