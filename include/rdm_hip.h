@@ -1,0 +1,170 @@
+/* librdm_hip.so - C ABI of the MI355X-native (gfx950) hot path of az16/MD_RDM.
+ *
+ * The reference is pure Python and has no FFI layer; the stable surface it
+ * offers is `network.RDM_Net.DepthEstimationNet` + `network.computations`.  This header is the
+ * INNER boundary a maintainer binds that surface to (see INTEGRATION.md for the ctypes stub):
+ * every entry point below names the reference code it replaces (file:line in /root/reference).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless marked host.
+ *  - the caller (PyTorch) owns every buffer; the library never allocates or frees device
+ *    memory and keeps no reference after return.  Workspace needs are answered by *_bytes().
+ *  - all work is enqueued on the caller's `hipStream_t`; no entry point synchronises the host.
+ *  - return 0 (RDM_OK) or a negative rdm_status; rdm_last_error_string() (thread-local) says why.
+ *    Nothing throws or aborts across the ABI.
+ *  - activations inside the conv stack are NHWC ("pixel-major"): element (b,y,x,c) of a tensor
+ *    with pixel stride `ld` lives at ((b*H + y)*W + x)*ld + c.  A tensor that is a channel slice
+ *    of a wider buffer simply has ld > channels (concat-free DenseNet blocks).
+ *  - packed conv weights are [tap = r*kw + s][out_channel][in_channel] (float32).
+ */
+#ifndef RDM_HIP_H_
+#define RDM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* rdm_stream_t; /* == hipStream_t */
+
+typedef enum rdm_status {
+  RDM_OK = 0,
+  RDM_ERR_BAD_ARGUMENT = -1,
+  RDM_ERR_WORKSPACE_TOO_SMALL = -2,
+  RDM_ERR_HIP = -3,
+  RDM_ERR_UNSUPPORTED = -4
+} rdm_status;
+
+const char* rdm_last_error_string(void);
+int rdm_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (fp32 MFMA implicit GEMM).  Replaces the nn.Conv2d / torchvision
+ * _DenseLayer / _Transition convolutions of network/RDM_Net.py:144,146-147,524-531 and the WSM
+ * convolutions of :163-236, plus their autograd-generated backward passes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rdm_conv_desc {
+  int32_t batch, in_h, in_w;     /* input extent */
+  int32_t in_c, in_ld;           /* contracted channels (multiple of 16) and input pixel stride */
+  int32_t out_c, out_ld;         /* output channels and output pixel stride */
+  int32_t kh, kw, stride_h, stride_w, pad_h, pad_w;
+} rdm_conv_desc;
+
+/* y[b,oy,ox,n] = bias[n] + sum_{r,s,c} f(x[b, oy*sh-ph+r, ox*sw-pw+s, c]) * w[r*kw+s][n][c]
+ * f = identity, or relu(x*bn_scale[c] + bn_shift[c]) when bn_scale != NULL (the BatchNorm+ReLU
+ * that precedes the conv in torchvision's _DenseLayer; zero padding applies AFTER f).
+ * stat_sum/stat_sq (optional, f64[out_c], pre-zeroed): += sum_m y and sum_m y^2 per channel. */
+int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
+                   const float* bn_scale, const float* bn_shift, float* y, double* stat_sum, double* stat_sq,
+                   rdm_stream_t stream);
+
+/* dx[b,y,x,c] = sum_{r,s,n} dy[b, y+ph-r, x+pw-s, n] * w[r*kw+s][n][c]      (stride 1 only)
+ * If mask_x != NULL the result is gated by relu'(mask_x*mask_scale+mask_shift) (the ReLU that fed
+ * the conv) and stat_a += sum_m dx, stat_b += sum_m dx*mask_x (BatchNorm-backward reductions). */
+int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld,
+                     const float* mask_x, int32_t mask_ld, const float* mask_scale, const float* mask_shift,
+                     double* stat_a, double* stat_b, rdm_stream_t stream);
+
+/* dw[r*kw+s][n][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * f(x[b, oy*sh-ph+r, ox*sw-pw+s, c]);  dw pre-zeroed. */
+int rdm_conv2d_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale,
+                     const float* bn_shift, float* dw_packed, rdm_stream_t stream);
+
+/* [out][in][kh][kw] (PyTorch) <-> [tap][out_pad][in] (packed); rows >= out_c are zero-filled. */
+int rdm_pack_conv_weight(const float* w_oihw, float* w_packed, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,
+                         int32_t out_c_padded, rdm_stream_t stream);
+int rdm_unpack_conv_weight(const float* w_packed, float* w_oihw, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,
+                           int32_t out_c_padded, rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The whole convolutional stack of DepthEstimationNet as one native plan:
+ *   network/RDM_Net.py:73-94 (encoder) + :150-159 (Decoder d_1 up to conv2), forward and backward,
+ *   train-mode (batch statistics + running-stat update) or eval-mode BatchNorm.
+ * `tensors` is a HOST array of rdm_net_num_tensors() device pointers, one per state_dict entry
+ * in the reference's registration order (rdm_net_tensor_name(i) gives the key); `grads` likewise
+ * (NULL entries = not wanted / buffers).  The workspace carries the saved activations from
+ * forward to backward, so the same workspace must be passed to both.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rdm_net rdm_net;
+
+int rdm_net_num_tensors(void);
+const char* rdm_net_tensor_name(int32_t i);
+int64_t rdm_net_tensor_numel(int32_t i);
+int rdm_net_tensor_is_param(int32_t i);          /* 1: float parameter, 0: buffer (running stats / counter) */
+
+int rdm_net_create(int32_t batch, int32_t height, int32_t width, rdm_net** out);
+void rdm_net_destroy(rdm_net* net);
+size_t rdm_net_workspace_bytes(const rdm_net* net);
+int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
+
+/* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */
+int rdm_net_forward(rdm_net* net, const float* x_nchw, void* const* tensors, void* workspace, size_t workspace_bytes,
+                    float* logits_nchw, int32_t training, rdm_stream_t stream);
+
+/* Backward in up to 4 segments so the caller can start reducing a segment's gradients (RCCL)
+ * while the next one computes: 0 = decoder d_1, 1 = dense_e4+trans_e4, 2 = dense_e3+trans_e3,
+ * 3 = dense_e2+trans_e2+conv_e1.  Segments must be run in order 0..3. */
+int rdm_net_backward(rdm_net* net, const float* dlogits_nchw, void* const* tensors, void* const* grads, void* workspace,
+                     size_t workspace_bytes, int32_t first_segment, int32_t last_segment, rdm_stream_t stream);
+/* (first,last) tensor index range whose gradients segment `seg` produces */
+int rdm_net_segment_range(int32_t seg, int32_t* first_tensor, int32_t* last_tensor);
+/* forward conv FLOPs (2*MAC) of one forward pass at this geometry, for roofline accounting */
+double rdm_net_forward_flops(const rdm_net* net);
+double rdm_net_backward_flops(const rdm_net* net);
+
+/* ------------------------------------------------------------------------------------------
+ * DORN ordinal head + ordinal loss.  RDM_Net.py:313-345 (DornOrdinalRegression), loss.py:8-59.
+ * ------------------------------------------------------------------------------------------ */
+/* logits (B,2K,H,W) f32 NCHW -> ord (B,K,H,W) f64, decode (B,1,H,W) i64 */
+int rdm_dorn_fwd(const float* logits, double* ord, int64_t* decode, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
+/* dlogits = d/dlogits sum(ord * dord) */
+int rdm_dorn_bwd(const float* logits, const double* dord, float* dlogits, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
+/* loss (1 float, pre-zeroed) = -(sum_{k<=t} log P + sum_{k>t} log(1-P)) / (B*HW), float32 logs */
+int rdm_ordinal_loss_fwd(const double* ord, const int32_t* target, float* loss, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
+int rdm_ordinal_loss_bwd(const double* ord, const int32_t* target, const float* dloss, double* dord, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
+/* utils.py:195-211 depth2label_sid on float64 depth: int32 labels */
+int rdm_depth2label_sid(const double* depth, int32_t* label, int64_t n, rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * network/computations.py post-processing (float64 unless noted)
+ * ------------------------------------------------------------------------------------------ */
+/* computations.py:308-311 resize: bicubic (A=-0.75, align_corners=False), (n,h,w) -> (n,oh,ow) */
+int rdm_resize_bicubic_f64(const double* src, double* dst, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, rdm_stream_t stream);
+/* computations.py:244-255 quick_gm fused with the division that every caller applies:
+ * dst[b,i] = src[b,i] / exp(exponent * sum_i log src[b,i]);  gm_out (optional) receives the means */
+int rdm_gm_normalize_f64(const double* src, double* dst, double* gm_out, int32_t batch, int32_t n, double exponent, rdm_stream_t stream);
+/* computations.py:368-392 decompose_depth_map: dn (B,S,S) -> levels packed smallest-first
+ * [d_0 (1x1) | F_1 (2x2) | ... | F_n (SxS)] per sample, sum_k 4^k doubles; S = 2^n <= 128 */
+int rdm_decompose_f64(const double* dn, double* levels, int32_t batch, int32_t n, int32_t relative_map, rdm_stream_t stream);
+/* computations.py:394-421 recombination + :423-484/:512-528 log/weight: out(B,2^n_out,2^n_out) =
+ * sum_k w[k] * nearest_up(log levels_k) for the packed pyramid above (levels 0..n_levels-1) */
+int rdm_recombine_f64(const double* levels, const float* w, double* out, int32_t batch, int32_t n_levels, int32_t n_out,
+                      int32_t take_log, rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Relative decoders (dormant in the reference graph, live as operators):
+ * ratio grid + Lloyd quantisation (RDM_Net.py:244-311, computations.py:269-295) and rank-1 ALS
+ * (computations.py:38-85,95-155,175-193), paging (:201-238).
+ * ------------------------------------------------------------------------------------------ */
+/* dense: R[b,i,j] = lloyd(d[b,i] * (1/d[b,j])), float32, S*S x S*S (sparse_comparison_v1) */
+int rdm_ratio_grid_lloyd_dense(const float* d, float* R, int32_t batch, int32_t n, const double* quant40, const double* inv41, rdm_stream_t stream);
+/* paged: dn (B,S,S) f32, dn_1 (B,S/2,S/2) f64 -> R (P,B,256,64) f64 per 16x16 page (P=(S/16)^2) */
+int rdm_ratio_grid_lloyd_paged(const float* dn, const double* dn_1, double* R, int32_t batch, int32_t s, const double* quant40,
+                               const double* inv41, int32_t quantize, rdm_stream_t stream);
+/* rank-1 ALS on `groups` independent calls of `batch` matrices (rows x cols, f64 or f32 input):
+ * p (groups,batch,rows) f32 = first-arg-min-rmse iterate / gm; rmse (groups, limit+1) f32 scratch */
+size_t rdm_als_workspace_bytes(int32_t groups, int32_t batch, int32_t rows, int32_t cols, int32_t limit);
+int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups, int32_t batch, int32_t rows, int32_t cols,
+                  int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: torch.optim.AdamW step of network/module.py:41 over flat buffers (one launch).
+ * ------------------------------------------------------------------------------------------ */
+int rdm_adamw_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, rdm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDM_HIP_H_ */

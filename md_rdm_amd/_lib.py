@@ -1,0 +1,107 @@
+"""ctypes binding of librdm_hip.so (the C ABI in include/rdm_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, this raises.
+PyTorch only provides device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdm_hip.so")
+
+c_f32p = C.c_void_p  # all device pointers travel as void*
+i32, i64, f32, f64, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """rdm_conv_desc"""
+    _fields_ = [(n, i32) for n in ("batch", "in_h", "in_w", "in_c", "in_ld", "out_c", "out_ld", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w")]
+
+
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "rdm_last_error_string": (C.c_char_p, []),
+    "rdm_version": (C.c_int, []),
+    "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_net_num_tensors": (C.c_int, []),
+    "rdm_net_tensor_name": (C.c_char_p, [i32]),
+    "rdm_net_tensor_numel": (i64, [i32]),
+    "rdm_net_tensor_is_param": (C.c_int, [i32]),
+    "rdm_net_create": (C.c_int, [i32, i32, i32, C.POINTER(vp)]),
+    "rdm_net_destroy": (None, [vp]),
+    "rdm_net_workspace_bytes": (sz, [vp]),
+    "rdm_net_output_hw": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "rdm_net_forward": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, i32, vp]),
+    "rdm_net_backward": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, sz, i32, i32, vp]),
+    "rdm_net_segment_range": (C.c_int, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    "rdm_net_forward_flops": (f64, [vp]),
+    "rdm_net_backward_flops": (f64, [vp]),
+    "rdm_dorn_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "rdm_dorn_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "rdm_ordinal_loss_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "rdm_ordinal_loss_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "rdm_depth2label_sid": (C.c_int, [vp, vp, i64, vp]),
+    "rdm_resize_bicubic_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_gm_normalize_f64": (C.c_int, [vp, vp, vp, i32, i32, f64, vp]),
+    "rdm_decompose_f64": (C.c_int, [vp, vp, i32, i32, vp]),
+    "rdm_fine_detail_pred_f32": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+    "rdm_fine_detail_pred_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+    "rdm_recombine_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_recombine_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_ratio_grid_lloyd_dense": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+    "rdm_ratio_grid_lloyd_paged": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
+    "rdm_als_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "rdm_als_rank1": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "rdm_page_split_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "rdm_page_reconstruct_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "rdm_adamw_fused": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+}
+
+_lib = None
+
+
+class RdmError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RdmError(f"{LIB_PATH} not found - run `python -m md_rdm_amd.build` (hipcc --offload-arch=gfx950). "
+                           "There is no CPU/PyTorch fallback for the hot path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)     # AttributeError here = header/library drift: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        raise RdmError(f"librdm_hip error {rc}: {lib().rdm_last_error_string().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise RdmError("non-contiguous tensor passed to the C ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,525 @@
+// HBM-bound helper kernels of the conv stack (NHWC, float4-vectorised, wave64):
+// BatchNorm statistics / finalisation / backward coefficients, transition pooling,
+// 3x3/s2 max-pool, im2col of the 7x7/s2 stem, layout packing, fused AdamW.
+// Reference call sites: network/RDM_Net.py:524-532 (stem, pool, pad_br, transitions),
+// torchvision _DenseLayer BatchNorm2d (third party), network/module.py:41 (AdamW).
+#include "rdm_common.h"
+#include "elementwise.h"
+
+namespace rdm {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------
+// per-channel reductions over rows of a [M][ld] matrix: 256 threads = 64 float4-columns x 4
+// row lanes; f32 partials per thread (<= rows_per_block/4 terms), f64 atomics per block.
+//   MODE 0: s0 = sum v, s1 = sum v^2
+//   MODE 1: v <- v * relu'(x*xs+xt) written back in place; s0 = sum v, s1 = sum v*x
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colreduce(float* V, int ldv, const float* X, int ldx, const float* xs, const float* xt,
+                                                   int M, int C, int rows_per_block, double* s0, double* s1) {
+  __shared__ float4 red0[256], red1[256];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
+  if (c < C) {
+    float4 sc = make_float4(0, 0, 0, 0), sh = sc;
+    if (MODE == 1) { sc = ld4(xs + c); sh = ld4(xt + c); }
+    for (int m = r0 + ry; m < r1; m += 4) {
+      float4 v = ld4(V + (long)m * ldv + c);
+      if (MODE == 0) {
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+        a1.x += v.x * v.x; a1.y += v.y * v.y; a1.z += v.z * v.z; a1.w += v.w * v.w;
+      } else {
+        const float4 x = ld4(X + (long)m * ldx + c);
+        v.x = fmaf(x.x, sc.x, sh.x) > 0.f ? v.x : 0.f;
+        v.y = fmaf(x.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
+        v.z = fmaf(x.z, sc.z, sh.z) > 0.f ? v.z : 0.f;
+        v.w = fmaf(x.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
+        st4(V + (long)m * ldv + c, v);
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+        a1.x += v.x * x.x; a1.y += v.y * x.y; a1.z += v.z * x.z; a1.w += v.w * x.w;
+      }
+    }
+  }
+  red0[threadIdx.x] = a0; red1[threadIdx.x] = a1;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int k = 1; k < 4; ++k) {
+      const float4 b0 = red0[cx + 64 * k], b1 = red1[cx + 64 * k];
+      a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+      a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    }
+    atomicAdd(s0 + c, (double)a0.x); atomicAdd(s0 + c + 1, (double)a0.y); atomicAdd(s0 + c + 2, (double)a0.z); atomicAdd(s0 + c + 3, (double)a0.w);
+    if (s1) { atomicAdd(s1 + c, (double)a1.x); atomicAdd(s1 + c + 1, (double)a1.y); atomicAdd(s1 + c + 2, (double)a1.z); atomicAdd(s1 + c + 3, (double)a1.w); }
+  }
+}
+
+int launch_colstats(const float* V, int ldv, int M, int C, double* sum, double* sq, hipStream_t s) {
+  const int rpb = 256;
+  dim3 grid(cdiv(C / 4, 64), cdiv(M, rpb));
+  hipLaunchKernelGGL(k_colreduce<0>, grid, dim3(256), 0, s, const_cast<float*>(V), ldv, nullptr, 0, nullptr, nullptr, M, C, rpb, sum, sq);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_mask_stats(float* V, int ldv, const float* X, int ldx, const float* xs, const float* xt, int M, int C, double* s0,
+                      double* s1, hipStream_t s) {
+  const int rpb = 256;
+  dim3 grid(cdiv(C / 4, 64), cdiv(M, rpb));
+  hipLaunchKernelGGL(k_colreduce<1>, grid, dim3(256), 0, s, V, ldv, X, ldx, xs, xt, M, C, rpb, s0, s1);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm finalisation: statistics -> (scale, shift) used by the consumer's conv prologue,
+// + running-stat update (momentum 0.1, unbiased variance) exactly as nn.BatchNorm2d.
+// ------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const double* sum, const double* sq, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, long long* num_batches, float* scale, float* shift,
+                              float* save_mean, float* save_rstd, int C, int training, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && num_batches) *num_batches += 1;
+  if (c >= C) return;
+  float mean, rstd;
+  if (training) {
+    const double mu = sum[c] / count;
+    double var = sq[c] / count - mu * mu;
+    if (var < 0) var = 0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  } else {
+    mean = running_mean[c];
+    rstd = 1.f / sqrtf(running_var[c] + eps);
+  }
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  save_mean[c] = mean;
+  save_rstd[c] = rstd;
+}
+
+int launch_bn_finalize(const double* sum, const double* sq, double count, const float* gamma, const float* beta, float* rm,
+                       float* rv, long long* nbt, float* scale, float* shift, float* save_mean, float* save_rstd, int C,
+                       int training, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, sum, sq, count, gamma, beta, rm, rv, nbt, scale, shift,
+                     save_mean, save_rstd, C, training, 0.1f, 1e-5f);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// BatchNorm backward coefficients: dx = A*dz + B*x + Cc (dz already ReLU-masked),
+// dgamma = sum dz*xhat, dbeta = sum dz.  s0 = sum dz, s1 = sum dz*x.
+__global__ void k_bn_bwd_coeffs(const double* s0, const double* s1, double count, const float* gamma, const float* mean,
+                                const float* rstd, float* A, float* Bc, float* Cc, float* dgamma, float* dbeta, int C, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = mean[c], rs = rstd[c], g = gamma[c];
+  const double sdz = s0[c], sdzx = s1[c];
+  const double sdzxhat = rs * (sdzx - mu * sdz);
+  if (dgamma) dgamma[c] = (float)sdzxhat;
+  if (dbeta) dbeta[c] = (float)sdz;
+  const double a = g * rs;
+  if (training) {
+    const double m1 = sdz / count, m2 = sdzxhat / count;
+    const double b = -a * rs * m2;
+    A[c] = (float)a; Bc[c] = (float)b; Cc[c] = (float)(-a * m1 - b * mu);
+  } else {
+    A[c] = (float)a; Bc[c] = 0.f; Cc[c] = 0.f;
+  }
+}
+
+int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const float* gamma, const float* mean, const float* rstd,
+                         float* A, float* Bc, float* Cc, float* dgamma, float* dbeta, int C, int training, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3(cdiv(C, 256)), dim3(256), 0, s, s0, s1, count, gamma, mean, rstd, A, Bc, Cc, dgamma, dbeta, C, training);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// dst (=|+=) A[c]*dz + B[c]*x + Cc[c]
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A,
+                                                 const float* Bc, const float* Cc, long total4, int C4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const float4 a = ld4(A + c), b = ld4(Bc + c), cc = ld4(Cc + c);
+    const float4 z = ld4(dz + m * ldz + c), xv = ld4(x + m * ldx + c);
+    float4 r;
+    r.x = fmaf(a.x, z.x, fmaf(b.x, xv.x, cc.x));
+    r.y = fmaf(a.y, z.y, fmaf(b.y, xv.y, cc.y));
+    r.z = fmaf(a.z, z.z, fmaf(b.z, xv.z, cc.z));
+    r.w = fmaf(a.w, z.w, fmaf(b.w, xv.w, cc.w));
+    float* d = dst + m * ldd + c;
+    if (ACC) { const float4 o = ld4(d); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+    st4(d, r);
+  }
+}
+
+int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A, const float* Bc,
+                   const float* Cc, int M, int C, bool accumulate, hipStream_t s) {
+  const long total4 = (long)M * (C / 4);
+  const int grid = (int)std::min<long>(cdiv(total4, 256), 256 * 16);
+  if (accumulate) hipLaunchKernelGGL(k_affine3<true>, dim3(grid), dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, A, Bc, Cc, total4, C / 4);
+  else hipLaunchKernelGGL(k_affine3<false>, dim3(grid), dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, A, Bc, Cc, total4, C / 4);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Transition front end (RDM_Net.py:527,529,531-532): ZeroPad2d((0,1,0,1)) -> BN -> ReLU -> 2x2
+// average.  The 1x1 conv is linear, so it is applied AFTER the pooling (4x fewer GEMM rows).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H,
+                                                    int W, int Ho, int Wo, int C4) {
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    long pix = i / C4;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const float4 s4 = ld4(sc + c), t4 = ld4(sh + c);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (y < H && x < W) v = ld4(X + ((long)(b * H + y) * W + x) * ldx + c);
+        acc.x += fmaxf(fmaf(v.x, s4.x, t4.x), 0.f);
+        acc.y += fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
+        acc.z += fmaxf(fmaf(v.z, s4.z, t4.z), 0.f);
+        acc.w += fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
+      }
+    acc.x *= 0.25f; acc.y *= 0.25f; acc.z *= 0.25f; acc.w *= 0.25f;
+    st4(P + i * 4, acc);
+  }
+}
+
+int launch_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(k_trans_pool, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, X, ldx, sc, sh, P, B, H, W, Ho, Wo, C / 4);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// backward, pass 1: reductions over the PADDED extent (H+1)x(W+1) (pad pixels are BN inputs).
+// dz(py,px) = 0.25 * dP(py/2,px/2) * [relu'(z)] when the position is covered by a pooling window.
+__global__ __launch_bounds__(256) void k_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const float* sc, const float* sh,
+                                                               int B, int H, int W, int Ho, int Wo, int C, int rows_per_block,
+                                                               double* s0, double* s1) {
+  __shared__ float4 red0[256], red1[256];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  const int Hp = H + 1, Wp = W + 1;
+  const long Mp = (long)B * Hp * Wp;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(Mp, r0 + rows_per_block);
+  float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+  if (c < C) {
+    const float4 s4 = ld4(sc + c), t4 = ld4(sh + c);
+    for (long m = r0 + ry; m < r1; m += 4) {
+      const int px = (int)(m % Wp);
+      const long t = m / Wp;
+      const int py = (int)(t % Hp), b = (int)(t / Hp);
+      if (py >= 2 * Ho || px >= 2 * Wo) continue;
+      float4 x = make_float4(0, 0, 0, 0);
+      if (py < H && px < W) x = ld4(X + ((long)(b * H + py) * W + px) * ldx + c);
+      const float4 g = ld4(dP + ((long)(b * Ho + (py >> 1)) * Wo + (px >> 1)) * C + c);
+      float4 dz;
+      dz.x = fmaf(x.x, s4.x, t4.x) > 0.f ? 0.25f * g.x : 0.f;
+      dz.y = fmaf(x.y, s4.y, t4.y) > 0.f ? 0.25f * g.y : 0.f;
+      dz.z = fmaf(x.z, s4.z, t4.z) > 0.f ? 0.25f * g.z : 0.f;
+      dz.w = fmaf(x.w, s4.w, t4.w) > 0.f ? 0.25f * g.w : 0.f;
+      a0.x += dz.x; a0.y += dz.y; a0.z += dz.z; a0.w += dz.w;
+      a1.x += dz.x * x.x; a1.y += dz.y * x.y; a1.z += dz.z * x.z; a1.w += dz.w * x.w;
+    }
+  }
+  red0[threadIdx.x] = a0; red1[threadIdx.x] = a1;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int k = 1; k < 4; ++k) {
+      const float4 b0 = red0[cx + 64 * k], b1 = red1[cx + 64 * k];
+      a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+      a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    }
+    atomicAdd(s0 + c, (double)a0.x); atomicAdd(s0 + c + 1, (double)a0.y); atomicAdd(s0 + c + 2, (double)a0.z); atomicAdd(s0 + c + 3, (double)a0.w);
+    atomicAdd(s1 + c, (double)a1.x); atomicAdd(s1 + c + 1, (double)a1.y); atomicAdd(s1 + c + 2, (double)a1.z); atomicAdd(s1 + c + 3, (double)a1.w);
+  }
+}
+
+// backward, pass 2: G[b,y,x,c] = A*dz + B*x + Cc on the real HxW extent (first writer of G)
+__global__ __launch_bounds__(256) void k_trans_pool_bwd_apply(const float* dP, const float* X, int ldx, const float* sc, const float* sh,
+                                                              const float* A, const float* Bc, const float* Cc, float* G, int ldg, int B,
+                                                              int H, int W, int Ho, int Wo, int C) {
+  const int C4 = C / 4;
+  const long total = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    long pix = i / C4;
+    const int x_ = (int)(pix % W); long t = pix / W;
+    const int y_ = (int)(t % H), b = (int)(t / H);
+    const float4 x = ld4(X + pix * ldx + c);
+    const float4 s4 = ld4(sc + c), t4 = ld4(sh + c);
+    float4 dz = make_float4(0, 0, 0, 0);
+    if (y_ < 2 * Ho && x_ < 2 * Wo) {
+      const float4 g = ld4(dP + ((long)(b * Ho + (y_ >> 1)) * Wo + (x_ >> 1)) * C + c);
+      dz.x = fmaf(x.x, s4.x, t4.x) > 0.f ? 0.25f * g.x : 0.f;
+      dz.y = fmaf(x.y, s4.y, t4.y) > 0.f ? 0.25f * g.y : 0.f;
+      dz.z = fmaf(x.z, s4.z, t4.z) > 0.f ? 0.25f * g.z : 0.f;
+      dz.w = fmaf(x.w, s4.w, t4.w) > 0.f ? 0.25f * g.w : 0.f;
+    }
+    const float4 a = ld4(A + c), bb = ld4(Bc + c), cc = ld4(Cc + c);
+    float4 r;
+    r.x = fmaf(a.x, dz.x, fmaf(bb.x, x.x, cc.x));
+    r.y = fmaf(a.y, dz.y, fmaf(bb.y, x.y, cc.y));
+    r.z = fmaf(a.z, dz.z, fmaf(bb.z, x.z, cc.z));
+    r.w = fmaf(a.w, dz.w, fmaf(bb.w, x.w, cc.w));
+    st4(G + pix * ldg + c, r);
+  }
+}
+
+int launch_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const float* sc, const float* sh, int B, int H, int W, int C,
+                                 double* s0, double* s1, hipStream_t s) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long Mp = (long)B * (H + 1) * (W + 1);
+  const int rpb = 256;
+  dim3 grid(cdiv(C / 4, 64), cdiv(Mp, rpb));
+  hipLaunchKernelGGL(k_trans_pool_bwd_reduce, grid, dim3(256), 0, s, dP, X, ldx, sc, sh, B, H, W, Ho, Wo, C, rpb, s0, s1);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_trans_pool_bwd_apply(const float* dP, const float* X, int ldx, const float* sc, const float* sh, const float* A,
+                                const float* Bc, const float* Cc, float* G, int ldg, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(k_trans_pool_bwd_apply, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, dP, X, ldx, sc, sh, A, Bc, Cc,
+                     G, ldg, B, H, W, Ho, Wo, C);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// stem: im2col for the 7x7/s2/p3 conv (RDM_Net.py:524), 3x3/s2/p1 max-pool (:525)
+// patches[m][k], k = c*49 + r*7 + s (PyTorch weight order), zero for k >= 147, row length 160
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_im2col_stem(const float* x, float* patches, int B, int H, int W, int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * 160;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % 160);
+    long m = i / 160;
+    float v = 0.f;
+    if (k < 147) {
+      const int ox = (int)(m % Wo); long t = m / Wo;
+      const int oy = (int)(t % Ho), b = (int)(t / Ho);
+      const int c = k / 49, rs = k - c * 49, r = rs / 7, q = rs - r * 7;
+      const int iy = oy * 2 - 3 + r, ix = ox * 2 - 3 + q;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long)(b * 3 + c) * H + iy) * W + ix];
+    }
+    patches[i] = v;
+  }
+}
+
+int launch_im2col_stem(const float* x, float* patches, int B, int H, int W, hipStream_t s) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const long total = (long)B * Ho * Wo * 160;
+  hipLaunchKernelGGL(k_im2col_stem, dim3((int)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, x, patches, B, H, W, Ho, Wo);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_maxpool3s2(const float* X, float* Y, int ldy, unsigned char* arg, int B, int H, int W, int Ho, int Wo, int C4) {
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    long pix = i / C4;
+    const int ox = (int)(pix % Wo); long t = pix / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 bi = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const float4 v = ld4(X + ((long)(b * H + iy) * W + ix) * (C4 * 4) + c);
+        const unsigned char t9 = (unsigned char)(r * 3 + q);
+        if (v.x > best.x) { best.x = v.x; bi.x = t9; }
+        if (v.y > best.y) { best.y = v.y; bi.y = t9; }
+        if (v.z > best.z) { best.z = v.z; bi.z = t9; }
+        if (v.w > best.w) { best.w = v.w; bi.w = t9; }
+      }
+    st4(Y + pix * ldy + c, best);
+    *reinterpret_cast<uchar4*>(arg + pix * (C4 * 4) + c) = bi;
+  }
+}
+
+int launch_maxpool3s2(const float* X, float* Y, int ldy, unsigned char* arg, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3s2, dim3((int)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, X, Y, ldy, arg, B, H, W, Ho, Wo, C / 4);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// gather form of the max-pool backward (no atomics): each input pixel collects from the <= 4 windows holding it
+__global__ __launch_bounds__(256) void k_maxpool3s2_bwd(const float* Gy, int ldg, const unsigned char* arg, float* Gx, int B, int H, int W,
+                                                        int Ho, int Wo, int C4) {
+  const long total = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    long pix = i / C4;
+    const int ix = (int)(pix % W); long t = pix / W;
+    const int iy = (int)(t % H), b = (int)(t / H);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int oy = max(0, iy / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy)
+      for (int ox = max(0, ix / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
+        const int r = iy - (2 * oy - 1), q = ix - (2 * ox - 1);
+        if (r < 0 || r > 2 || q < 0 || q > 2) continue;
+        const unsigned char t9 = (unsigned char)(r * 3 + q);
+        const long op = (long)(b * Ho + oy) * Wo + ox;
+        const uchar4 a = *reinterpret_cast<const uchar4*>(arg + op * (C4 * 4) + c);
+        const float4 g = ld4(Gy + op * ldg + c);
+        if (a.x == t9) acc.x += g.x;
+        if (a.y == t9) acc.y += g.y;
+        if (a.z == t9) acc.z += g.z;
+        if (a.w == t9) acc.w += g.w;
+      }
+    st4(Gx + pix * (C4 * 4) + c, acc);
+  }
+}
+
+int launch_maxpool3s2_bwd(const float* Gy, int ldg, const unsigned char* arg, float* Gx, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3s2_bwd, dim3((int)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, Gy, ldg, arg, Gx, B, H, W, Ho, Wo, C / 4);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout helpers
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_w(const float* w, float* wp, int O, int I, int T, int Opad) {
+  const long total = (long)T * Opad * I;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % I); long t = i / I;
+    const int o = (int)(t % Opad), tap = (int)(t / Opad);
+    wp[i] = o < O ? w[((long)o * I + c) * T + tap] : 0.f;
+  }
+}
+__global__ void k_unpack_w(const float* wp, float* w, int O, int I, int T, int Opad) {
+  const long total = (long)O * I * T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int tap = (int)(i % T); long t = i / T;
+    const int c = (int)(t % I), o = (int)(t / I);
+    w[i] = wp[((long)tap * Opad + o) * I + c];
+  }
+}
+int launch_pack_w(const float* w, float* wp, int O, int I, int T, int Opad, hipStream_t s) {
+  const long total = (long)T * Opad * I;
+  hipLaunchKernelGGL(k_pack_w, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wp, O, I, T, Opad);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_unpack_w(const float* wp, float* w, int O, int I, int T, int Opad, hipStream_t s) {
+  const long total = (long)O * I * T;
+  hipLaunchKernelGGL(k_unpack_w, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, wp, w, O, I, T, Opad);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// [M][ld] (first C columns) -> (B,C,HW) and back (zero-filling columns C..ld-1)
+__global__ void k_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int p = (int)(i % HW); long t = i / HW;
+    const int c = (int)(t % C), b = (int)(t / C);
+    dst[i] = src[((long)b * HW + p) * ld + c];
+  }
+}
+__global__ void k_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW) {
+  const long total = (long)B * HW * ld;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % ld); long m = i / ld;
+    const int p = (int)(m % HW), b = (int)(m / HW);
+    dst[i] = c < C ? src[((long)b * C + c) * HW + p] : 0.f;
+  }
+}
+int launch_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int C, int HW, hipStream_t s) {
+  const long total = (long)B * C * HW;
+  hipLaunchKernelGGL(k_nhwc_to_nchw, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, src, ld, dst, B, C, HW);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_nchw_to_nhwc(const float* src, float* dst, int ld, int B, int C, int HW, hipStream_t s) {
+  const long total = (long)B * HW * ld;
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, src, dst, ld, B, C, HW);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+__global__ void k_f64_to_f32(const double* src, float* dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+int launch_f64_to_f32(const double* src, float* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_f64_to_f32, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, module.py:41)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adamw(float* p, const float* g, float* m, float* v, long n4, long n, float lr, float b1, float b2,
+                                               float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+    float* P = &pp.x; float* Gv = &gg.x; float* Mv = &mm.x; float* Vv = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = Gv[k] * gscale;
+      float w = P[k] * (1.f - lr * wd);
+      Mv[k] = b1 * Mv[k] + (1.f - b1) * gr;
+      Vv[k] = b2 * Vv[k] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(Vv[k]) * rsqrt_bc2 + eps;
+      w -= (lr / bc1) * (Mv[k] / denom);
+      P[k] = w;
+    }
+    st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = n4 * 4 + threadIdx.x;
+    const float gr = g[i] * gscale;
+    float w = p[i] * (1.f - lr * wd);
+    m[i] = b1 * m[i] + (1.f - b1) * gr;
+    v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+    w -= (lr / bc1) * (m[i] / (sqrtf(v[i]) * rsqrt_bc2 + eps));
+    p[i] = w;
+  }
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                 float gscale, hipStream_t s) {
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_adamw, dim3((int)std::min<long>(std::max<long>(cdiv(n4, 256), 1), 256 * 8)), dim3(256), 0, s, p, g, m, v, n4, n, lr, b1, b2,
+                     eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace rdm

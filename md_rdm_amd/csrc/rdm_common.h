@@ -1,0 +1,81 @@
+// Shared internals of librdm_hip.so (gfx950 only).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/rdm_hip.h"
+
+namespace rdm {
+
+void set_error(const char* fmt, ...);
+
+#define RDM_CHECK_ARG(cond, ...)                         \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      ::rdm::set_error(__VA_ARGS__);                     \
+      return RDM_ERR_BAD_ARGUMENT;                       \
+    }                                                    \
+  } while (0)
+
+#define RDM_HIP_OK(expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      ::rdm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RDM_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+// every launcher ends with this: catches bad launch configs without synchronising
+#define RDM_LAUNCH_OK()                                                               \
+  do {                                                                                \
+    hipError_t e_ = hipGetLastError();                                                \
+    if (e_ != hipSuccess) {                                                           \
+      ::rdm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RDM_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------
+// internal launchers (igemm.hip) - the C-ABI conv entry points and the network plan
+// both go through these
+// ---------------------------------------------------------------------------------
+struct ConvGeom {
+  int B, H, W;          // input spatial extent (pixels the A operand is gathered from)
+  int Ho, Wo;           // output spatial extent (GEMM rows M = B*Ho*Wo)
+  int KH, KW, SH, SW, PH, PW;
+  int dir;              // +1: iy = oy*SH - PH + r (forward);  -1: iy = oy + PH - r (dgrad of a stride-1 conv)
+};
+
+enum Epilogue { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_MASK_STATS = 2, EPI_ATOMIC = 3 };
+
+struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[tap][n][c]     (B_KSTRIDED=false)
+                            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[tap][c][n]     (B_KSTRIDED=true, dgrad)
+  ConvGeom g;
+  const float* A; int lda; int C;             // contracted channels per tap (multiple of 16)
+  const float* a_scale; const float* a_shift; // optional BN-ReLU prologue on A (per contracted channel)
+  const float* Wt; long wtap; int ldw;        // weight tap stride / row stride (floats)
+  float* out; int ldc; int M, N;
+  const float* bias;                          // EPI_STORE only
+  double* stat0; double* stat1;               // STORE_STATS: sum v, sum v^2;  MASK_STATS: sum dz, sum dz*x
+  const float* X; int ldx; const float* x_scale; const float* x_shift;  // MASK_STATS: forward pre-BN value + its affine
+  int split_k;                                // >1 => EPI_ATOMIC into pre-zeroed out
+};
+
+struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)][c])
+  ConvGeom g;
+  const float* G; int ldg; int N;             // gradient wrt conv output, rows n
+  const float* Xs; int ldx; int C;            // forward conv input (pre BN-ReLU), rows c
+  const float* x_scale; const float* x_shift; // optional BN-ReLU prologue (per c)
+  float* dW; long wtap; int ldw;              // pre-zeroed, atomically accumulated
+  int split_k;
+};
+
+int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
+int pick_split_k(long tiles, long kslabs);
+
+}  // namespace rdm
