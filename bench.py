@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth-maps/s of one full training step (forward + losses + backward +
+AdamW) of DepthEstimationNet at NYU geometry 228x304, batch 16 per GPU (BASELINE.json metric /
+configs[2]), synthetic data, deterministic hash-filled weights, fp32 (exact-f32 MFMA).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+
+One JSON line on rank 0, with
+  roofline     - the dominant kernel family (fp32 MFMA implicit-GEMM convs): algorithmic conv FLOPs
+                 of the step / summed kernel time measured with HIP events on the launch stream
+  cpu_baseline - the oracle (CPU restatement of the reference, oracle/) timed on the host cores on a
+                 bounded sample (batch 2 train steps) - a reported baseline, never the thing shipped.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--height", type=int, default=228)
+    ap.add_argument("--width", type=int, default=304)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from md_rdm_amd import _lib, filler, harness, parallel
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    L = _lib.lib()
+
+    model = DepthEstimationNet()
+    filler.fill_state_dict(model.state_dict())
+    model = model.to(dev)
+    model.train()
+    B, H, W = args.batch, args.height, args.width
+    x, y = filler.synthetic_batch(B, H, W, seed=1234 + rank)
+    xg, yg = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    model.flatten_parameters()
+    sync = parallel.attach(model)
+    opt = harness.FusedAdamW(model, lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        loss, _ = harness.training_step(model, xg, yg)
+        loss.backward()
+        scale = sync.finish()
+        opt.step(grad_scale=scale)
+        return loss
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model ready, workspace {model._plan(B, H, W)[1] / 2**30:.2f} GiB")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        note(f"warmup {i} done")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_roofline:
+        L.rdm_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    roof = None
+    if not args.no_roofline:
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(L.rdm_profile_read(C.byref(ms), C.byref(fl), C.byref(n)))
+        L.rdm_profile_enable(0)
+        h = model._plan(B, H, W)[0]
+        algo = (L.rdm_net_forward_flops(h) + L.rdm_net_backward_flops(h)) * args.steps   # reference-algorithmic conv FLOPs
+        achieved = algo / (ms.value * 1e-3) / 1e12
+        peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
+        roof = {"bound": "mfma", "kernel": "conv_fwd_kernel/conv_wgrad_kernel (fp32 MFMA 16x16x4 implicit GEMM)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": n.value // max(args.steps, 1), "kernel_ms_per_step": round(ms.value / args.steps, 3),
+                "executed_tflop_per_step": round(fl.value / args.steps / 1e12, 4), "algorithmic_tflop_per_step": round(algo / args.steps / 1e12, 4)}
+
+    note(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(H, W)
+        note("cpu baseline done")
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        out = {"metric": "depth-maps/sec NYU 228x304 batch=16 fwd+bwd", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"NYU-v2 {H}x{W} batch={B}/GPU full train step (fwd+losses+bwd+AdamW), DepthEstimationNet 90.5M params",
+                          "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss.item())},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(H, W, batch=2, iters=2):
+    """The oracle's training step (PyTorch-CPU restatement of the reference) on the host cores."""
+    import numpy as np
+    from md_rdm_amd import filler
+    from oracle import rdm_net_cpu as onet
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, int(os.environ.get("RDM_CPU_THREADS", "16"))))     # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(n)
+    sd = onet.new_state_dict(filler.state_value)
+    x, y = filler.synthetic_batch(batch, H, W, seed=1234)
+    xt = torch.from_numpy(x)
+    onet.training_step(sd, xt, y)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        onet.training_step(sd, xt, y)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} train steps (fwd+losses+bwd, no optimizer) at batch {batch}, {H}x{W}, fp32, after 1 warm-up"}
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,13 @@ typedef enum rdm_status {
 const char* rdm_last_error_string(void);
 int rdm_version(void);
 
+/* Per-launch HIP-event timing of the MFMA conv kernels (bench.py's roofline leg).  While enabled,
+ * every conv launch is bracketed by events on its own stream; rdm_profile_read() synchronises on
+ * them (HOST sync - never call it inside a graph capture), returns the summed kernel time (ms),
+ * the FLOPs those launches executed and their count, and clears the record. */
+void rdm_profile_enable(int32_t on);
+int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM).  Replaces the nn.Conv2d / torchvision
  * _DenseLayer / _Transition convolutions of network/RDM_Net.py:144,146-147,524-531 and the WSM
@@ -109,6 +116,9 @@ int rdm_net_backward(rdm_net* net, const float* dlogits_nchw, void* const* tenso
                      size_t workspace_bytes, int32_t first_segment, int32_t last_segment, rdm_stream_t stream);
 /* (first,last) tensor index range whose gradients segment `seg` produces */
 int rdm_net_segment_range(int32_t seg, int32_t* first_tensor, int32_t* last_tensor);
+/* test/debug access to the workspace layout: byte offset + float count of a named internal buffer
+ * ("blk0".."blk3" block activations NHWC, "G0".."G3" their gradients, "logits", "Y<b>_<i>" bottlenecks ...) */
+int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, int64_t* numel);
 /* forward conv FLOPs (2*MAC) of one forward pass at this geometry, for roofline accounting */
 double rdm_net_forward_flops(const rdm_net* net);
 double rdm_net_backward_flops(const rdm_net* net);
@@ -134,13 +144,19 @@ int rdm_resize_bicubic_f64(const double* src, double* dst, int32_t n, int32_t h,
 /* computations.py:244-255 quick_gm fused with the division that every caller applies:
  * dst[b,i] = src[b,i] / exp(exponent * sum_i log src[b,i]);  gm_out (optional) receives the means */
 int rdm_gm_normalize_f64(const double* src, double* dst, double* gm_out, int32_t batch, int32_t n, double exponent, rdm_stream_t stream);
-/* computations.py:368-392 decompose_depth_map: dn (B,S,S) -> levels packed smallest-first
- * [d_0 (1x1) | F_1 (2x2) | ... | F_n (SxS)] per sample, sum_k 4^k doubles; S = 2^n <= 128 */
-int rdm_decompose_f64(const double* dn, double* levels, int32_t batch, int32_t n, int32_t relative_map, rdm_stream_t stream);
-/* computations.py:394-421 recombination + :423-484/:512-528 log/weight: out(B,2^n_out,2^n_out) =
- * sum_k w[k] * nearest_up(log levels_k) for the packed pyramid above (levels 0..n_levels-1) */
-int rdm_recombine_f64(const double* levels, const float* w, double* out, int32_t batch, int32_t n_levels, int32_t n_out,
-                      int32_t take_log, rdm_stream_t stream);
+/* computations.py:368-392 decompose_depth_map: dn (B,S,S), S = 2^n <= 128 -> pyramid packed
+ * smallest-first per sample: [d_0 (1x1) | F_1 (2x2) | ... | F_n (SxS)], (4^(n+1)-1)/3 doubles;
+ * level k starts at (4^k-1)/3.  (relative_map=True callers simply ignore slot 0.) */
+int rdm_decompose_f64(const double* dn, double* levels, int32_t batch, int32_t n, rdm_stream_t stream);
+/* computations.py:423-484 + :512-528 with one candidate per level (the live graph, RDM_Net.py:126-133):
+ * yhat_k = float32(log levels_k) * w[k], packed like `levels` (n_levels = n+1), float32 */
+int rdm_fine_detail_pred_f32(const double* levels, const float* w, float* yhat, int32_t batch, int32_t n_levels, rdm_stream_t stream);
+/* dw[k] = sum dyhat_k * float32(log levels_k)   (gradient of the 4 Weights scalars, RDM_Net.py:443-491) */
+int rdm_fine_detail_pred_bwd(const double* levels, const float* dyhat, float* dw, int32_t batch, int32_t n_levels, rdm_stream_t stream);
+/* computations.py:394-421 recombination: out (B,2^n_out,2^n_out) f64 = sum_{k>=first_level} nearest_up(yhat_k),
+ * first_level = 0 when the list starts with d_0 (1x1), 1 for relative-only lists */
+int rdm_recombine_f64(const float* yhat, double* out, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream);
+int rdm_recombine_bwd(const double* dout, float* dyhat, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relative decoders (dormant in the reference graph, live as operators):
@@ -157,6 +173,11 @@ int rdm_ratio_grid_lloyd_paged(const float* dn, const double* dn_1, double* R, i
 size_t rdm_als_workspace_bytes(int32_t groups, int32_t batch, int32_t rows, int32_t cols, int32_t limit);
 int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups, int32_t batch, int32_t rows, int32_t cols,
                   int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+
+/* computations.py:201-216 split_matrix: (B,S,S) -> (P,B,page,page) row-major pages, P = (S/page)^2 */
+int rdm_page_split_f32(const float* src, float* pages, int32_t batch, int32_t s, int32_t page, rdm_stream_t stream);
+/* computations.py:218-238 reconstruct, bug-as-spec: out[b,y,x] = pages[y/page][b, y%page, x%page] */
+int rdm_page_reconstruct_f32(const float* pages, float* out, int32_t batch, int32_t s, int32_t page, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.AdamW step of network/module.py:41 over flat buffers (one launch).

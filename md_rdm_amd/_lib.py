@@ -22,6 +22,8 @@ _SIGNATURES = {
     # name: (restype, [argtypes])
     "rdm_last_error_string": (C.c_char_p, []),
     "rdm_version": (C.c_int, []),
+    "rdm_profile_enable": (None, [i32]),
+    "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
@@ -38,6 +40,7 @@ _SIGNATURES = {
     "rdm_net_forward": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, i32, vp]),
     "rdm_net_backward": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, sz, i32, i32, vp]),
     "rdm_net_segment_range": (C.c_int, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    "rdm_net_buffer": (C.c_int, [vp, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]),
     "rdm_net_forward_flops": (f64, [vp]),
     "rdm_net_backward_flops": (f64, [vp]),
     "rdm_dorn_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),

@@ -1,0 +1,300 @@
+// Relative-depth decoders: pairwise depth-ratio grids, Lloyd quantisation, rank-1 ALS, paging.
+//   network/RDM_Net.py:244-257  sparse_comparison_v1      :259-284 sparse_comparison_id
+//   network/RDM_Net.py:286-311  LloydQuantization          computations.py:269-295 get_resized_area
+//   computations.py:38-85,95-155,175-193 quadratic_als / alternating_least_squares / als_step
+//   computations.py:201-238     split_matrix / reconstruct
+//
+// The reference builds each 256x64 grid with 256 Python iterations, quantises it with a
+// (B,256,64,40) CPU label tensor + a per-element Python loop, and runs ALS as ~1400 tiny launches
+// per page.  Here: one coalesced kernel writes the quantised grid (each output element is
+// computed from <= 2 scalars, so the kernel is a pure HBM write stream), and ALS keeps one
+// matrix per workgroup resident in LDS (256x64 f32 = 64 KB of CDNA4's 160 KB) for all
+// iterations - R is read from HBM exactly once (compulsory traffic), every matvec is
+// wavefront-reduced on chip.
+#include <algorithm>
+
+#include "rdm_common.h"
+
+namespace rdm {
+
+__device__ __forceinline__ int lloyd_index_f64(double r, const double* __restrict__ q) {
+  int idx = 0;
+#pragma unroll 8
+  for (int i = 0; i < 40; ++i) idx += (r >= q[i]) ? 1 : 0;
+  return idx;
+}
+
+// R[b,i,j] = lloyd(d_i * (1/d_j)) in float32 (thresholds rounded to float32, as torch compares a
+// float32 tensor with a python scalar)
+__global__ void k_ratio_dense(const float* __restrict__ d, float* __restrict__ R, int B, int n, const double* __restrict__ quant, const double* __restrict__ inv) {
+  __shared__ float q32[40];
+  __shared__ float inv32[41];
+  if (threadIdx.x < 40) q32[threadIdx.x] = (float)quant[threadIdx.x];
+  if (threadIdx.x < 41) inv32[threadIdx.x] = (float)inv[threadIdx.x];
+  __syncthreads();
+  const long total = (long)B * n * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % n);
+    const long t = i / n;
+    const int r_ = (int)(t % n), b = (int)(t / n);
+    const float v = d[(long)b * n + r_] * (1.0f / d[(long)b * n + j]);
+    int idx = 0;
+#pragma unroll 8
+    for (int k = 0; k < 40; ++k) idx += (v >= q32[k]) ? 1 : 0;
+    R[i] = inv32[idx];
+  }
+}
+
+// paged grid: page p=(pi,pj) of the SxS map, fine pixel (r,c) of the 16x16 page against the 8x8
+// coarse page; only the 3x3 window at clamp(r/2,0,5),clamp(c/2,0,5) holds coarse depths, the
+// rest of `area` is 1 (so those entries are dn itself).  float64 like the reference.
+__global__ void k_ratio_paged(const float* __restrict__ dn, const double* __restrict__ dn1, double* __restrict__ R, int B, int S, const double* __restrict__ quant,
+                              const double* __restrict__ inv, int quantize) {
+  __shared__ double q[40];
+  __shared__ double iv[41];
+  if (threadIdx.x < 40) q[threadIdx.x] = quant[threadIdx.x];
+  if (threadIdx.x < 41) iv[threadIdx.x] = inv[threadIdx.x];
+  __syncthreads();
+  const int ratio = S / 16, S1 = S / 2;
+  const long total = (long)ratio * ratio * B * 256 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 63);
+    const int fine = (int)((i >> 6) & 255);
+    const long t = i >> 14;
+    const int b = (int)(t % B), p = (int)(t / B);
+    const int pi = p / ratio, pj = p - pi * ratio;
+    const int r = fine >> 4, c = fine & 15;
+    const int jr = j >> 3, jc = j & 7;
+    const int rs = min(max(r >> 1, 0), 5), cs = min(max(c >> 1, 0), 5);
+    const double v = (double)dn[((long)b * S + (16 * pi + r)) * S + 16 * pj + c];
+    double area = 1.0;
+    if (jr >= rs && jr <= rs + 2 && jc >= cs && jc <= cs + 2) area = dn1[((long)b * S1 + (8 * pi + jr)) * S1 + 8 * pj + jc];
+    double val = v * (1.0 / area);
+    if (quantize) val = iv[lloyd_index_f64(val, q)];
+    R[i] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank-1 ALS, one matrix per workgroup, resident in LDS.  ROWS in {64, 256}, 64 columns.
+//   p = (R q) / (q.q + 0.05);  rmse_k recorded after each p-update;  q = (R' p) / (p.p + 0.05)
+//   with R' = R.view(cols, rows) - a REINTERPRETATION of the same buffer (computations.py:133).
+// ------------------------------------------------------------------------------------------------
+template <int ROWS>
+__device__ __forceinline__ float block_sum_f(float v, float* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[wv] = v;
+  __syncthreads();
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) r += sh[i];
+  return r;
+}
+
+template <int ROWS, bool F64IN>
+__global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, float* __restrict__ hist, double* __restrict__ sse, int batch, int limit) {
+  constexpr int COLS = 64, LD = 68, Q = ROWS / COLS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* R = smem;                   // [ROWS][LD]
+  float* p = R + ROWS * LD;          // [ROWS]
+  float* q = p + ROWS;               // [COLS]
+  float* red = q + COLS;             // [8]
+  const int t = threadIdx.x;
+  const long mat = blockIdx.x;       // = group * batch + b
+  const int group = (int)(mat / batch), b = (int)(mat % batch);
+  // coalesced load of the matrix (read from HBM exactly once)
+  for (int i = t; i < ROWS * COLS; i += ROWS) {
+    float v;
+    if (F64IN) v = (float)static_cast<const double*>(Rin)[mat * ROWS * COLS + i];
+    else v = static_cast<const float*>(Rin)[mat * ROWS * COLS + i];
+    R[(i >> 6) * LD + (i & 63)] = v;
+  }
+  p[t] = 1.f;
+  if (t < COLS) q[t] = 1.f;
+  __syncthreads();
+  const float4* row = reinterpret_cast<const float4*>(R + t * LD);
+  float* H = hist + mat * (long)(limit + 1) * ROWS;
+  double* S = sse + ((long)group * (limit + 1)) * batch + b;
+  float pi = 1.f;
+  for (int it = 0; it <= limit; ++it) {
+    if (it > 0) {
+      // p-update
+      float qq = 0.f, bi = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < COLS / 4; ++c4) {
+        const float4 rv = row[c4];
+        const float4 qv = reinterpret_cast<const float4*>(q)[c4];
+        bi += rv.x * qv.x + rv.y * qv.y + rv.z * qv.z + rv.w * qv.w;
+        qq += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+      }
+      pi = bi * (1.0f / (qq + 0.05f));
+    }
+    // residual of the current (p, q) pair
+    float e = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < COLS / 4; ++c4) {
+      const float4 rv = row[c4];
+      const float4 qv = reinterpret_cast<const float4*>(q)[c4];
+      const float d0 = pi * qv.x - rv.x, d1 = pi * qv.y - rv.y, d2 = pi * qv.z - rv.z, d3 = pi * qv.w - rv.w;
+      e += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    H[(long)it * ROWS + t] = pi;
+    const float etot = block_sum_f<ROWS>(e, red);
+    if (t == 0) S[(long)it * batch] = (double)etot;
+    if (it == limit) break;
+    // q-update: thread t owns row t of R == flat elements [t*64, t*64+64) == R'[t/Q][(t%Q)*64 ...]
+    p[t] = pi;
+    const float pp = block_sum_f<ROWS>(pi * pi, red);      // also orders the p[] writes before the reads below
+    const float* pseg = p + (t % Q) * COLS;
+    float part = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < COLS / 4; ++c4) {
+      const float4 rv = row[c4];
+      const float4 pv = reinterpret_cast<const float4*>(pseg)[c4];
+      part += rv.x * pv.x + rv.y * pv.y + rv.z * pv.z + rv.w * pv.w;
+    }
+    if (Q == 4) { part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); }
+    __syncthreads();                                         // all reads of q[] (this iteration) are done
+    if (t % Q == 0) q[t / Q] = part * (1.0f / (pp + 0.05f));
+    __syncthreads();
+  }
+}
+
+// rmse_k = float(sqrt(sum_b sse / (B*rows*cols))); first arg-min (rmse_record.index(min(...)))
+__global__ void k_als_select(const double* __restrict__ sse, int* __restrict__ kstar, float* __restrict__ rmse_out, int batch, int limit, double count) {
+  const int g = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float best = INFINITY;
+  int bi = 0;
+  for (int k = 0; k <= limit; ++k) {
+    double s = 0;
+    for (int b = 0; b < batch; ++b) s += sse[((long)g * (limit + 1) + k) * batch + b];
+    const float r = (float)sqrt(s / count);
+    if (rmse_out) rmse_out[(long)g * (limit + 1) + k] = r;
+    if (r < best) { best = r; bi = k; }
+  }
+  kstar[g] = bi;
+}
+
+// out = p_k* / quick_gm(p_k*, rows)  with the reference's exponent 1/rows^2 (computations.py:248-249)
+template <int ROWS>
+__global__ __launch_bounds__(ROWS) void k_als_finish(const float* __restrict__ hist, const int* __restrict__ kstar, float* __restrict__ out, int batch, int limit) {
+  __shared__ float red[8];
+  const long mat = blockIdx.x;
+  const int g = (int)(mat / batch);
+  const float v = hist[(mat * (limit + 1) + kstar[g]) * ROWS + threadIdx.x];
+  const float s = block_sum_f<ROWS>(logf(v), red);
+  const float gm = expf(s / (float)(ROWS * ROWS));
+  out[mat * ROWS + threadIdx.x] = v / gm;
+}
+
+__global__ void k_page_split(const float* __restrict__ src, float* __restrict__ pages, int B, int S, int page) {
+  const int ratio = S / page;
+  const long total = (long)B * S * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % page); long t = i / page;
+    const int y = (int)(t % page); t /= page;
+    const int b = (int)(t % B), p = (int)(t / B);
+    const int pi = p / ratio, pj = p - pi * ratio;
+    pages[i] = src[((long)b * S + pi * page + y) * S + pj * page + x];
+  }
+}
+
+__global__ void k_page_reconstruct(const float* __restrict__ pages, float* __restrict__ out, int B, int S, int page) {
+  const long total = (long)B * S * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % S); long t = i / S;
+    const int y = (int)(t % S), b = (int)(t / S);
+    const int p = y / page;                                  // bug-as-spec: every column block reuses pages 0..ratio-1
+    out[i] = pages[(((long)p * B + b) * page + (y % page)) * page + (x % page)];
+  }
+}
+
+static size_t als_hist_bytes(int groups, int batch, int rows, int limit) { return ((size_t)groups * batch * (limit + 1) * rows * 4 + 255) & ~(size_t)255; }
+static size_t als_sse_bytes(int groups, int batch, int limit) { return ((size_t)groups * (limit + 1) * batch * 8 + 255) & ~(size_t)255; }
+
+}  // namespace rdm
+
+using namespace rdm;
+
+extern "C" {
+
+int rdm_ratio_grid_lloyd_dense(const float* d, float* R, int32_t batch, int32_t n, const double* quant40, const double* inv41, rdm_stream_t stream) {
+  RDM_CHECK_ARG(d && R && quant40 && inv41 && batch > 0 && n > 0, "ratio_grid_lloyd_dense: bad argument");
+  const long total = (long)batch * n * n;
+  hipLaunchKernelGGL(k_ratio_dense, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, stream, d, R, batch, n, quant40, inv41);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_ratio_grid_lloyd_paged(const float* dn, const double* dn_1, double* R, int32_t batch, int32_t s, const double* quant40, const double* inv41,
+                               int32_t quantize, rdm_stream_t stream) {
+  RDM_CHECK_ARG(dn && dn_1 && R && quant40 && inv41 && batch > 0, "ratio_grid_lloyd_paged: bad argument");
+  RDM_CHECK_ARG(s >= 16 && s % 16 == 0 && s <= 1024, "ratio_grid_lloyd_paged: side (%d) must be a multiple of 16", s);
+  const long total = (long)(s / 16) * (s / 16) * batch * 256 * 64;
+  hipLaunchKernelGGL(k_ratio_paged, dim3((int)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, stream, dn, dn_1, R, batch, s, quant40, inv41, quantize);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+size_t rdm_als_workspace_bytes(int32_t groups, int32_t batch, int32_t rows, int32_t cols, int32_t limit) {
+  if (groups <= 0 || batch <= 0 || rows <= 0 || limit < 0) return 0;
+  (void)cols;
+  return als_hist_bytes(groups, batch, rows, limit) + als_sse_bytes(groups, batch, limit) + (((size_t)groups * 4 + 255) & ~(size_t)255) +
+         (((size_t)groups * (limit + 1) * 4 + 255) & ~(size_t)255);
+}
+
+int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups, int32_t batch, int32_t rows, int32_t cols, int32_t limit,
+                  void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(R && p_out && workspace && groups > 0 && batch > 0 && limit >= 0, "als_rank1: bad argument");
+  RDM_CHECK_ARG(cols == 64 && (rows == 64 || rows == 256), "als_rank1: supported shapes are 256x64 (paged) and 64x64 (quadratic), got %dx%d", rows, cols);
+  const size_t need = rdm_als_workspace_bytes(groups, batch, rows, cols, limit);
+  if (workspace_bytes < need) { set_error("als_rank1: workspace too small: %zu < %zu", workspace_bytes, need); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "als_rank1: workspace must be 256-byte aligned");
+  char* w = static_cast<char*>(workspace);
+  float* hist = reinterpret_cast<float*>(w); w += als_hist_bytes(groups, batch, rows, limit);
+  double* sse = reinterpret_cast<double*>(w); w += als_sse_bytes(groups, batch, limit);
+  int* kstar = reinterpret_cast<int*>(w); w += ((size_t)groups * 4 + 255) & ~(size_t)255;
+  float* rmse = reinterpret_cast<float*>(w);
+  const int nmat = groups * batch;
+  const size_t lds = (size_t)(rows * 68 + rows + 64 + 8) * sizeof(float);
+  if (rows == 256) {
+    if (r_is_f64) {
+      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_als<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_als<256, true>), dim3(nmat), dim3(256), lds, stream, R, hist, sse, batch, limit);
+    } else {
+      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_als<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_als<256, false>), dim3(nmat), dim3(256), lds, stream, R, hist, sse, batch, limit);
+    }
+  } else {
+    if (r_is_f64) hipLaunchKernelGGL((k_als<64, true>), dim3(nmat), dim3(64), lds, stream, R, hist, sse, batch, limit);
+    else hipLaunchKernelGGL((k_als<64, false>), dim3(nmat), dim3(64), lds, stream, R, hist, sse, batch, limit);
+  }
+  RDM_LAUNCH_OK();
+  hipLaunchKernelGGL(k_als_select, dim3(groups), dim3(64), 0, stream, sse, kstar, rmse, batch, limit, (double)batch * rows * cols);
+  RDM_LAUNCH_OK();
+  if (rows == 256) hipLaunchKernelGGL((k_als_finish<256>), dim3(nmat), dim3(256), 0, stream, hist, kstar, p_out, batch, limit);
+  else hipLaunchKernelGGL((k_als_finish<64>), dim3(nmat), dim3(64), 0, stream, hist, kstar, p_out, batch, limit);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_page_split_f32(const float* src, float* pages, int32_t batch, int32_t s, int32_t page, rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && pages && batch > 0 && page > 0 && s >= page && s % page == 0, "page_split: bad argument");
+  const long total = (long)batch * s * s;
+  hipLaunchKernelGGL(k_page_split, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, stream, src, pages, batch, s, page);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_page_reconstruct_f32(const float* pages, float* out, int32_t batch, int32_t s, int32_t page, rdm_stream_t stream) {
+  RDM_CHECK_ARG(pages && out && batch > 0 && page > 0 && s >= page && s % page == 0, "page_reconstruct: bad argument");
+  const long total = (long)batch * s * s;
+  hipLaunchKernelGGL(k_page_reconstruct, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, stream, pages, out, batch, s, page);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,14 @@ extern "C" {
 const char* rdm_last_error_string(void) { return g_err; }
 int rdm_version(void) { return 100; }
 
+void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
+int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches) {
+  int n = 0;
+  int rc = profile_read(conv_ms, conv_flops, &n);
+  if (launches) *launches = n;
+  return rc;
+}
+
 int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
                    float* y, double* stat_sum, double* stat_sq, rdm_stream_t stream) {
   ConvGeom g;

@@ -1,0 +1,156 @@
+// DORN ordinal head, ordinal loss and SID labels - tiny HBM/latency-bound kernels.
+//   network/RDM_Net.py:313-345  DornOrdinalRegression (clamp f32 -> f64 pair softmax -> count)
+//   loss.py:8-59                Ordinal_Loss.calc
+//   utils.py:195-211            depth2label_sid
+// The reference spends ~8 launches + a masked-select host sync on these; here each is one launch.
+#include <algorithm>
+
+#include "rdm_common.h"
+
+namespace rdm {
+
+// one thread per (b, pixel): walks the K pairs; loads are coalesced across pixels (NCHW)
+__global__ void k_dorn_fwd(const float* __restrict__ x, double* __restrict__ ord, long long* __restrict__ decode, int B, int K, int HW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const int b = i / HW, p = i - b * HW;
+  const float* xb = x + (long)b * 2 * K * HW + p;
+  double* ob = ord + (long)b * K * HW + p;
+  int count = 0;
+  for (int k = 0; k < K; ++k) {
+    const float fa = fminf(fmaxf(xb[(long)(2 * k) * HW], 1e-8f), 1e4f);
+    const float fb = fminf(fmaxf(xb[(long)(2 * k + 1) * HW], 1e-8f), 1e4f);
+    const double a = (double)fa, bb = (double)fb;
+    const double m = fmax(a, bb);
+    const double ea = exp(a - m), eb = exp(bb - m);
+    const double P = eb / (ea + eb);
+    ob[(long)k * HW] = P;
+    count += (P > 0.5) ? 1 : 0;
+  }
+  decode[i] = count;
+}
+
+__global__ void k_dorn_bwd(const float* __restrict__ x, const double* __restrict__ dord, float* __restrict__ dx, int B, int K, int HW) {
+  const long total = (long)B * K * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const long t = i / HW;
+    const int k = (int)(t % K), b = (int)(t / K);
+    const long ia = ((long)b * 2 * K + 2 * k) * HW + p, ib = ia + HW;
+    const float xa = x[ia], xb = x[ib];
+    const double a = (double)fminf(fmaxf(xa, 1e-8f), 1e4f), bb = (double)fminf(fmaxf(xb, 1e-8f), 1e4f);
+    const double m = fmax(a, bb);
+    const double ea = exp(a - m), eb = exp(bb - m);
+    const double P = eb / (ea + eb);
+    const double tt = dord[i] * P * (1.0 - P);
+    // clamp backward passes the gradient where min <= x <= max
+    dx[ia] = (xa >= 1e-8f && xa <= 1e4f) ? (float)(-tt) : 0.f;
+    dx[ib] = (xb >= 1e-8f && xb <= 1e4f) ? (float)tt : 0.f;
+  }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_ordinal_loss_fwd(const double* __restrict__ P, const int* __restrict__ target, float* loss, int B, int K, int HW) {
+  __shared__ double sh[4];
+  const long total = (long)B * K * HW;
+  double acc = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long t = i / HW;
+    const int k = (int)(t % K), b = (int)(t / K);
+    const int tg = target[(long)b * HW + p];
+    const double v = P[i];
+    const double q = (k <= tg) ? v : 1.0 - v;
+    acc += (double)logf((float)fmin(fmax(q, 1e-8), 1e8));
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, (float)(r / -(double)((long)B * HW)));
+}
+
+__global__ void k_ordinal_loss_bwd(const double* __restrict__ P, const int* __restrict__ target, const float* __restrict__ dloss, double* __restrict__ dP,
+                                   int B, int K, int HW) {
+  const long total = (long)B * K * HW;
+  const double scale = (double)dloss[0] / -(double)((long)B * HW);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const long t = i / HW;
+    const int k = (int)(t % K), b = (int)(t / K);
+    const int tg = target[(long)b * HW + p];
+    const double v = P[i];
+    const bool lower = k <= tg;
+    const double q = lower ? v : 1.0 - v;
+    double g = 0;
+    if (q >= 1e-8 && q <= 1e8) g = (double)(1.0f / (float)q);       // d log(float(q)) ; clamp gate
+    dP[i] = lower ? scale * g : -scale * g;
+  }
+}
+
+// utils.py:195-211 with the reference's dtype quirks: alpha = float32(0.02), K = float32(90),
+// log(beta/alpha) evaluated in float32 (= 0x1.8dbc24p+2); tensor arithmetic in float64.
+__global__ void k_depth2label_sid(const double* __restrict__ d, int* __restrict__ label, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double alpha = 0x1.47ae14p-6, den = 0x1.8dbc24p+2;
+  double l = 90.0 * log(d[i] / alpha) / den;
+  l = fmax(l, 0.0);            // NaN (d < 0) propagates like torch.max -> int conversion is UB in both; d > 0 by construction
+  label[i] = (int)l;
+}
+
+}  // namespace rdm
+
+using namespace rdm;
+
+extern "C" {
+
+int rdm_dorn_fwd(const float* logits, double* ord, int64_t* decode, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(logits && ord && decode && batch > 0 && k > 0 && hw > 0, "dorn_fwd: bad argument");
+  const int n = batch * hw;
+  hipLaunchKernelGGL(k_dorn_fwd, dim3(cdiv(n, 64)), dim3(64), 0, stream, logits, ord, reinterpret_cast<long long*>(decode), batch, k, hw);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_dorn_bwd(const float* logits, const double* dord, float* dlogits, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(logits && dord && dlogits && batch > 0 && k > 0 && hw > 0, "dorn_bwd: bad argument");
+  const long total = (long)batch * k * hw;
+  hipLaunchKernelGGL(k_dorn_bwd, dim3((int)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, stream, logits, dord, dlogits, batch, k, hw);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_ordinal_loss_fwd(const double* ord, const int32_t* target, float* loss, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(ord && target && loss && batch > 0 && k > 0 && hw > 0, "ordinal_loss_fwd: bad argument");
+  RDM_HIP_OK(hipMemsetAsync(loss, 0, sizeof(float), stream));
+  const long total = (long)batch * k * hw;
+  hipLaunchKernelGGL(k_ordinal_loss_fwd, dim3((int)std::min<long>(cdiv(total, 256), 256)), dim3(256), 0, stream, ord, target, loss, batch, k, hw);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_ordinal_loss_bwd(const double* ord, const int32_t* target, const float* dloss, double* dord, int32_t batch, int32_t k, int32_t hw,
+                         rdm_stream_t stream) {
+  RDM_CHECK_ARG(ord && target && dloss && dord && batch > 0 && k > 0 && hw > 0, "ordinal_loss_bwd: bad argument");
+  const long total = (long)batch * k * hw;
+  hipLaunchKernelGGL(k_ordinal_loss_bwd, dim3((int)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, stream, ord, target, dloss, dord, batch, k, hw);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_depth2label_sid(const double* depth, int32_t* label, int64_t n, rdm_stream_t stream) {
+  RDM_CHECK_ARG(depth && label && n >= 0, "depth2label_sid: bad argument");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(k_depth2label_sid, dim3(cdiv(n, 256)), dim3(256), 0, stream, depth, label, (long)n);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+}  // extern "C"

@@ -20,6 +20,8 @@
 //    of its block buffer in place), so normalised activations never exist in HBM.
 //  * Epilogues: store (+bias), store + per-channel sum/sum^2 (f64 atomics) for the next
 //    BatchNorm, ReLU-mask + BN-backward reductions for dgrad, f32 atomics for split-K.
+#include <vector>
+
 #include "rdm_common.h"
 
 namespace rdm {
@@ -362,6 +364,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events recorded on the
+// launch stream around every conv kernel; read back (and summed) by rdm_profile_read().
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+} g_prof;
+struct ProfScope {
+  hipStream_t s; double flops; hipEvent_t a{}, b{}; bool on;
+  ProfScope(hipStream_t s_, double f) : s(s_), flops(f), on(g_prof.on) { if (on) { a = g_prof.get(); b = g_prof.get(); hipEventRecord(a, s); } }
+  ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops}); } }
+};
+}  // namespace
+
+void profile_enable(bool on) { g_prof.on = on; }
+int profile_read(double* ms, double* flops, int* launches) {
+  double t = 0, f = 0;
+  for (auto& r : g_prof.recs) {
+    RDM_HIP_OK(hipEventSynchronize(r.b));
+    float e = 0;
+    RDM_HIP_OK(hipEventElapsedTime(&e, r.a, r.b));
+    t += e; f += r.flops;
+    g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
+  }
+  if (ms) *ms = t;
+  if (flops) *flops = f;
+  if (launches) *launches = (int)g_prof.recs.size();
+  g_prof.recs.clear();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
 int pick_split_k(long tiles, long kslabs) {
@@ -415,6 +456,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
   }
   a.split_k = split;
+  ProfScope prof(s, 2.0 * a.M * a.N * (double)kslabs * 16);
 
 #define RDM_FWD_DISPATCH(TAPS_, BKS_)                                                           \
   switch (epi) {                                                                               \
@@ -452,6 +494,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
   if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs);
+  ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
   if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
   else launch_wgrad_cfg<4, 3, 2, 2>(a, taps, s);          // 128 x 96
   RDM_LAUNCH_OK();

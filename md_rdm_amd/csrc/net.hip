@@ -418,6 +418,26 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w) {
   return RDM_OK;
 }
 
+/* debug / test access to the plan's workspace layout: byte offset and float count of a named buffer
+ * ("blk0".."blk3", "G0".."G3", "logits", "e1", "dZ", "dZ1", "Y<b>_<i>", "bn1_<b>_<i>", "bn2_<b>_<i>", "P<t>") */
+int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, int64_t* numel) {
+  RDM_CHECK_ARG(net && name && offset_bytes && numel, "NULL argument");
+  const NetImpl& n = *reinterpret_cast<const NetImpl*>(net);
+  int b = -1, i = -1;
+  if (sscanf(name, "blk%d", &b) == 1 && b >= 0 && b < 4) { *offset_bytes = n.blk[b]; *numel = (int64_t)n.bg[b].M * n.bg[b].ctot; return RDM_OK; }
+  if (sscanf(name, "G%d", &b) == 1 && b >= 0 && b < 4) { *offset_bytes = n.G[b]; *numel = (int64_t)n.bg[b].M * n.bg[b].ctot; return RDM_OK; }
+  if (sscanf(name, "Y%d_%d", &b, &i) == 2 && b >= 0 && b < 4 && i >= 0 && i < kBlocks[b].layers) { *offset_bytes = n.lws[b][i].Y; *numel = (int64_t)n.bg[b].M * n.bg[b].cb; return RDM_OK; }
+  if (sscanf(name, "bn1_%d_%d", &b, &i) == 2 && b >= 0 && b < 4 && i >= 0 && i < kBlocks[b].layers) { *offset_bytes = n.lws[b][i].bn1; *numel = 4 * (int64_t)(kBlocks[b].cin + i * GROWTH); return RDM_OK; }
+  if (sscanf(name, "bn2_%d_%d", &b, &i) == 2 && b >= 0 && b < 4 && i >= 0 && i < kBlocks[b].layers) { *offset_bytes = n.lws[b][i].bn2; *numel = 4 * (int64_t)n.bg[b].cb; return RDM_OK; }
+  if (sscanf(name, "P%d", &b) == 1 && b >= 0 && b < 3) { *offset_bytes = n.transP[b]; *numel = (int64_t)n.bg[b + 1].M * kTrans[b].cin; return RDM_OK; }
+  if (!strcmp(name, "logits")) { *offset_bytes = n.logits; *numel = (int64_t)n.bg[3].M * 192; return RDM_OK; }
+  if (!strcmp(name, "e1")) { *offset_bytes = n.e1; *numel = (int64_t)n.M1 * 96; return RDM_OK; }
+  if (!strcmp(name, "dZ")) { *offset_bytes = n.dZ; *numel = 0; for (int k = 0; k < 4; ++k) *numel = std::max<int64_t>(*numel, (int64_t)n.bg[k].M * n.bg[k].cb); return RDM_OK; }
+  if (!strcmp(name, "dZ1")) { *offset_bytes = n.dZ1; *numel = 0; for (int k = 0; k < 4; ++k) *numel = std::max<int64_t>(*numel, (int64_t)n.bg[k].M * n.bg[k].ctot); return RDM_OK; }
+  set_error("rdm_net_buffer: unknown buffer '%s'", name);
+  return RDM_ERR_BAD_ARGUMENT;
+}
+
 double rdm_net_forward_flops(const rdm_net* net) {
   if (!net) return 0;
   const NetImpl* n = reinterpret_cast<const NetImpl*>(net);

@@ -1,0 +1,238 @@
+// network/computations.py post-processing as single-launch float64 kernels (HBM/latency bound,
+// a few KB..MB per call; the reference issues ~25 tiny ATen launches + Python loops for these):
+//   resize (:308-311)  quick_gm (:244-255)  decompose_depth_map (:368-392)
+//   relative_fine_detail_matrix/make_matrix (:423-484) + make_pred (:512-528)  recombination (:394-421)
+#include <algorithm>
+
+#include "rdm_common.h"
+
+namespace rdm {
+
+// Keys cubic convolution, A = -0.75 (ATen upsample_bicubic2d)
+__device__ __forceinline__ void cubic_coeffs(double t, double (&c)[4]) {
+  const double A = -0.75;
+  const double x0 = t + 1.0, x3 = 2.0 - t, x2 = 1.0 - t;
+  c[0] = ((A * x0 - 5.0 * A) * x0 + 8.0 * A) * x0 - 4.0 * A;
+  c[1] = ((A + 2.0) * t - (A + 3.0)) * t * t + 1.0;
+  c[2] = ((A + 2.0) * x2 - (A + 3.0)) * x2 * x2 + 1.0;
+  c[3] = ((A * x3 - 5.0 * A) * x3 + 8.0 * A) * x3 - 4.0 * A;
+}
+
+// align_corners=False, no antialias, border indices clamped
+__device__ __forceinline__ double bicubic_at(const double* __restrict__ src, int h, int w, int oh, int ow, int oy, int ox) {
+  const double sy = (double)h / oh, sx = (double)w / ow;
+  const double fy = sy * (oy + 0.5) - 0.5, fx = sx * (ox + 0.5) - 0.5;
+  const double fly = floor(fy), flx = floor(fx);
+  const int iy = (int)fly, ix = (int)flx;
+  double cy[4], cx[4];
+  cubic_coeffs(fy - fly, cy);
+  cubic_coeffs(fx - flx, cx);
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = min(max(iy - 1 + i, 0), h - 1);
+    double row = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = min(max(ix - 1 + j, 0), w - 1);
+      row += src[y * w + x] * cx[j];
+    }
+    r += row * cy[i];
+  }
+  return r;
+}
+
+__global__ void k_resize_bicubic(const double* __restrict__ src, double* __restrict__ dst, int n, int h, int w, int oh, int ow) {
+  const long total = (long)n * oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % ow);
+    const long t = i / ow;
+    const int oy = (int)(t % oh), b = (int)(t / oh);
+    dst[i] = bicubic_at(src + (long)b * h * w, h, w, oh, ow, oy, ox);
+  }
+}
+
+__device__ __forceinline__ double block_sum_bcast(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[wv] = v;
+  __syncthreads();
+  double r = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+
+// one workgroup per sample: gm = exp(e * sum log x) (wavefront-reduced), dst = src / gm
+__global__ __launch_bounds__(256) void k_gm_normalize(const double* __restrict__ src, double* __restrict__ dst, double* __restrict__ gm_out, int n, double e) {
+  __shared__ double sh[4];
+  const double* s = src + (long)blockIdx.x * n;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += log(s[i]);
+  const double gm = exp(e * block_sum_bcast(acc, sh));
+  if (gm_out && threadIdx.x == 0) gm_out[blockIdx.x] = gm;
+  if (dst) {
+    double* d = dst + (long)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i] / gm;
+  }
+}
+
+__host__ __device__ __forceinline__ long level_off(int k) { return ((1L << (2 * k)) - 1) / 3; }
+
+// one workgroup per sample walks the pyramid top-down inside the packed output:
+// slot_k first holds d_k, then is divided in place by the nearest-upsampled d_{k-1}
+__global__ __launch_bounds__(256) void k_decompose(const double* __restrict__ dn, double* __restrict__ levels, int n) {
+  const int S = 1 << n;
+  const long per = level_off(n + 1);
+  double* L = levels + (long)blockIdx.x * per;
+  const double* src = dn + (long)blockIdx.x * S * S;
+  double* top = L + level_off(n);
+  for (int i = threadIdx.x; i < S * S; i += 256) top[i] = src[i];
+  __syncthreads();
+  for (int k = n; k >= 1; --k) {
+    const int s = 1 << k, h = s >> 1;
+    double* cur = L + level_off(k);
+    double* low = L + level_off(k - 1);
+    for (int i = threadIdx.x; i < h * h; i += 256) low[i] = bicubic_at(cur, s, s, h, h, i / h, i % h);
+    __syncthreads();
+    for (int i = threadIdx.x; i < s * s; i += 256) cur[i] = cur[i] / low[((i / s) >> 1) * h + ((i % s) >> 1)];
+    __syncthreads();
+  }
+}
+
+// y_hat_k = float(log F_k) * w_k   (single-candidate make_pred: A^T.float() @ w.float())
+__global__ void k_fine_detail_pred(const double* __restrict__ levels, const float* __restrict__ w, float* __restrict__ yhat, int batch, int n_levels) {
+  const long per = level_off(n_levels);
+  const long total = (long)batch * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long j = i % per;
+    int k = 0;
+    while (level_off(k + 1) <= j) ++k;
+    yhat[i] = (float)log(levels[i]) * w[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fine_detail_pred_bwd(const double* __restrict__ levels, const float* __restrict__ dyhat, float* __restrict__ dw, int batch,
+                                                              int n_levels) {
+  __shared__ double sh[4];
+  const int k = blockIdx.x;                      // one workgroup per level
+  const long per = level_off(n_levels), off = level_off(k), cnt = 1L << (2 * k);
+  double acc = 0;
+  for (long i = threadIdx.x; i < (long)batch * cnt; i += 256) {
+    const long b = i / cnt, j = i - b * cnt;
+    acc += (double)dyhat[b * per + off + j] * (double)(float)log(levels[b * per + off + j]);
+  }
+  const double r = block_sum_bcast(acc, sh);
+  if (threadIdx.x == 0) dw[k] = (float)r;
+}
+
+__global__ void k_recombine(const float* __restrict__ yhat, double* __restrict__ out, int batch, int n_levels, int n_out, int first_level) {
+  const int S = 1 << n_out;
+  const long per = level_off(n_levels);
+  const long total = (long)batch * S * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % S);
+    const long t = i / S;
+    const int y = (int)(t % S), b = (int)(t / S);
+    const float* Y = yhat + (long)b * per;
+    double r = 0.0;
+    bool have = false;
+    const int lo = first_level == 0 ? 1 : first_level;
+    for (int k = lo; k < n_levels; ++k) {
+      const int sh = n_out - k, s = 1 << k;
+      const double v = (double)Y[level_off(k) + (y >> sh) * s + (x >> sh)];
+      r = have ? r + v : v;
+      have = true;
+    }
+    if (first_level == 0) { const double d0 = (double)Y[0]; r = have ? d0 + r : d0; }
+    out[i] = r;
+  }
+}
+
+// d yhat_k[b, yy, xx] = sum over the 2^(n_out-k) square footprint of dout; one wave64 per output
+// element (lanes stride the footprint, shuffle-reduce in f64)
+__global__ __launch_bounds__(256) void k_recombine_bwd(const double* __restrict__ dout, float* __restrict__ dyhat, int batch, int n_levels, int n_out,
+                                                       int first_level) {
+  const int S = 1 << n_out;
+  const long per = level_off(n_levels);
+  const long total = (long)batch * per;
+  const int lane = threadIdx.x & 63;
+  for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (long)gridDim.x * 4) {
+    const long b = i / per, j = i - b * per;
+    int k = 0;
+    while (level_off(k + 1) <= j) ++k;
+    double acc = 0;
+    if (k >= first_level) {
+      const int s = 1 << k, sh = n_out - k, f = 1 << sh;
+      const long e = j - level_off(k);
+      const int yy = (int)(e / s), xx = (int)(e % s);
+      const double* D = dout + b * S * S + (long)(yy << sh) * S + (xx << sh);
+      for (int t = lane; t < f * f; t += 64) acc += D[(long)(t >> sh) * S + (t & (f - 1))];
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    }
+    if (lane == 0) dyhat[i] = (float)acc;
+  }
+}
+
+}  // namespace rdm
+
+using namespace rdm;
+
+extern "C" {
+
+int rdm_resize_bicubic_f64(const double* src, double* dst, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "resize_bicubic: bad argument");
+  const long total = (long)n * oh * ow;
+  hipLaunchKernelGGL(k_resize_bicubic, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, stream, src, dst, n, h, w, oh, ow);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_gm_normalize_f64(const double* src, double* dst, double* gm_out, int32_t batch, int32_t n, double exponent, rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && (dst || gm_out) && batch > 0 && n > 0, "gm_normalize: bad argument");
+  hipLaunchKernelGGL(k_gm_normalize, dim3(batch), dim3(256), 0, stream, src, dst, gm_out, n, exponent);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_decompose_f64(const double* dn, double* levels, int32_t batch, int32_t n, rdm_stream_t stream) {
+  RDM_CHECK_ARG(dn && levels && batch > 0 && n >= 0 && n <= 7, "decompose: need 0 <= n <= 7 (side 2^n <= 128)");
+  hipLaunchKernelGGL(k_decompose, dim3(batch), dim3(256), 0, stream, dn, levels, n);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_fine_detail_pred_f32(const double* levels, const float* w, float* yhat, int32_t batch, int32_t n_levels, rdm_stream_t stream) {
+  RDM_CHECK_ARG(levels && w && yhat && batch > 0 && n_levels >= 1 && n_levels <= 8, "fine_detail_pred: bad argument");
+  const long total = (long)batch * level_off(n_levels);
+  hipLaunchKernelGGL(k_fine_detail_pred, dim3((int)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, stream, levels, w, yhat, batch, n_levels);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_fine_detail_pred_bwd(const double* levels, const float* dyhat, float* dw, int32_t batch, int32_t n_levels, rdm_stream_t stream) {
+  RDM_CHECK_ARG(levels && dyhat && dw && batch > 0 && n_levels >= 1 && n_levels <= 8, "fine_detail_pred_bwd: bad argument");
+  hipLaunchKernelGGL(k_fine_detail_pred_bwd, dim3(n_levels), dim3(256), 0, stream, levels, dyhat, dw, batch, n_levels);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_recombine_f64(const float* yhat, double* out, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream) {
+  RDM_CHECK_ARG(yhat && out && batch > 0 && n_levels >= 1 && n_levels <= 8 && n_out >= n_levels - 1 && n_out <= 10 && first_level >= 0 && first_level < n_levels,
+                "recombine: bad argument");
+  const long total = (long)batch << (2 * n_out);
+  hipLaunchKernelGGL(k_recombine, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, stream, yhat, out, batch, n_levels, n_out, first_level);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_recombine_bwd(const double* dout, float* dyhat, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream) {
+  RDM_CHECK_ARG(dout && dyhat && batch > 0 && n_levels >= 1 && n_levels <= 8 && n_out >= n_levels - 1 && n_out <= 10 && first_level >= 0 && first_level < n_levels,
+                "recombine_bwd: bad argument");
+  const long total = (long)batch * level_off(n_levels);
+  hipLaunchKernelGGL(k_recombine_bwd, dim3((int)std::min<long>(cdiv(total, 4), 4096)), dim3(256), 0, stream, dout, dyhat, batch, n_levels, n_out, first_level);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+}  // extern "C"

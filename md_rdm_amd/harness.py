@@ -1,0 +1,92 @@
+"""The training/validation step of the reference's Lightning module (network/module.py:49-149),
+restated without Lightning so that it runs on this stack: same target preparation, same loss sum,
+AdamW(lr) as in ``configure_optimizers`` (:38-47).  ``train.py``'s flags are mirrored in
+md_rdm_amd/train.py."""
+import torch
+
+from . import loss as l
+from . import utils as u
+from .network import computations as cp
+from .network.RDM_Net import DepthEstimationNet
+
+
+def normalize(batch):
+    """module.py:145-149: divide by the geometric mean, exponent 1/H**2 (quick_gm squares its arg)."""
+    B, C, H, W = batch.size()
+    return cp.gm_normalize(batch, 1.0 / (H * H))
+
+
+def prepare_target(y):
+    """module.py:68,75-78: bicubic to 128x128, invalid pixels -> 1e-4."""
+    y = cp.resize(y, 128)
+    mask1 = y > 0
+    mask2 = (y <= 0) + 1e-4
+    return (y * mask1) + mask2
+
+
+def compute_final_depth(fine_detail_list, target, has_ordinal):
+    """module.py:119-133."""
+    component_target = cp.decompose_depth_map([], normalize(target), 7)[::-1]
+    if has_ordinal:
+        ord_components = cp.decompose_depth_map([], normalize(u.depth2label_sid(cp.resize(target, 8), cuda=True)), 3)[::-1]
+        component_target[0] = ord_components[0]
+    components, loss = cp.optimize_components(fine_detail_list, component_target, True)
+    final = cp.recombination(components)
+    return final, loss
+
+
+def compute_ordinal_target(ord_pred, target):
+    """module.py:135-143; for non-square head outputs (where the reference raises) the target is
+    resized to the head's (h, w)."""
+    h, w = ord_pred.shape[2], ord_pred.shape[3]
+    target = cp.resize(target, h if h == w else (h, w))
+    return u.depth2label_sid(target, cuda=True)
+
+
+def training_step(model, x, y):
+    """module.py:64-97 without logging.  Returns (loss_all, dict of components)."""
+    y = prepare_target(y)
+    fine_details, ord_depth_pred, ord_label_pred = model(x)
+    has_ordinal = fine_details[0].shape[2] == 1
+    y_hat = list(fine_details)                      # recombination pops from the list it is given (computations.py:405-407)
+    final_depth, fine_detail_loss = compute_final_depth(fine_details, y, has_ordinal=has_ordinal)
+    ord_y = compute_ordinal_target(ord_depth_pred, y)
+    ord_loss = l.Ordinal_Loss().calc(ord_label_pred, ord_y, cuda=True)
+    mse = torch.nn.functional.mse_loss(final_depth, y)
+    loss_all = mse + fine_detail_loss + ord_loss
+    return loss_all, dict(mse=mse, fine_detail_loss=fine_detail_loss, ord_loss=ord_loss, final_depth=final_depth, y=y, ord_y=ord_y,
+                          fine_details=y_hat, ord_depth_pred=ord_depth_pred, ord_label_pred=ord_label_pred)
+
+
+def validation_step(model, x, y):
+    """module.py:99-117: returns (y_hat, normalized target)."""
+    y = prepare_target(y)
+    fine_details, _, _ = model(x)
+    has_ordinal = fine_details[0].shape[2] == 1
+    y_hat, _ = compute_final_depth(fine_details, y, has_ordinal=has_ordinal)
+    return y_hat, normalize(y)
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(lr) semantics (module.py:41) as ONE launch over the model's flat parameter /
+    gradient buffers + a tiny torch step for the 4 Weights scalars."""
+
+    def __init__(self, model: DepthEstimationNet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.m = self.v = None
+        self.small = torch.optim.AdamW([p for p in model.weight_layer.parameters() if p.requires_grad], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def zero_grad(self):
+        self.small.zero_grad(set_to_none=True)
+
+    def step(self, grad_scale=1.0):
+        from . import _lib
+        flat, gflat, _ = self.model._flat
+        if self.m is None or self.m.data_ptr() == 0 or self.m.numel() != flat.numel():
+            self.m = torch.zeros_like(flat)
+            self.v = torch.zeros_like(flat)
+        self.step_count += 1
+        _lib.check(_lib.lib().rdm_adamw_fused(_lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(self.m), _lib.ptr(self.v), flat.numel(), self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.wd, self.step_count, float(grad_scale), _lib.stream()))
+        self.small.step()

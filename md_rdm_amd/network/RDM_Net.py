@@ -1,0 +1,368 @@
+"""MI355X-native ``DepthEstimationNet`` - same nn.Module surface as the reference
+``network/RDM_Net.py`` (no-arg constructor :26, ``forward(x) -> (y_hat, x_d1, ord_labels)`` :70-135,
+968-key ``state_dict``, module globals ``use_cuda`` / ``freeze_encoder`` :8-9), but every op of the
+hot path is a hand-written gfx950 kernel reached through the C ABI in ``include/rdm_hip.h``:
+
+  * the whole conv stack (encoder + decoder d_1 up to conv2) is ONE autograd node that runs the
+    native plan ``rdm_net_forward`` / ``rdm_net_backward`` (md_rdm_amd/csrc/net.hip);
+  * the DORN head, geometric-mean normalisation, decomposition and weighting are single launches.
+
+The nn.Conv2d / nn.BatchNorm2d objects below are *parameter holders only* (names, shapes and
+PyTorch's default initialisation, so checkpoints interchange); their ``forward`` is never called.
+There is no PyTorch/CPU fallback: without librdm_hip.so or without a GPU, ``forward`` raises.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import scipy.io
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import computations as cp
+
+use_cuda = True
+freeze_encoder = False
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+GROWTH = 48
+
+
+class BaseModel(nn.Module):
+    def load(self, path):
+        """Reference stub (RDM_Net.py:10-22): intentionally does nothing."""
+        pass
+
+
+# ------------------------------------------------------------------------------------------
+# parameter holders with torchvision's naming (denselayer%d / norm1 relu1 conv1 norm2 relu2 conv2;
+# norm relu conv pool), see tests/golden/state_dict_keys.txt
+# ------------------------------------------------------------------------------------------
+class _DenseLayerParams(nn.Module):
+    def __init__(self, cin, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.conv1 = nn.Conv2d(cin, bn_size * GROWTH, kernel_size=1, stride=1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * GROWTH)
+        self.conv2 = nn.Conv2d(bn_size * GROWTH, GROWTH, kernel_size=3, stride=1, padding=1, bias=False)
+
+
+class _DenseBlockParams(nn.Module):
+    """torchvision ``_DenseBlock(num_layers, num_input_features, bn_size, growth_rate=48, ...)``.
+    The reference passes the spatial size as bn_size (57/29/15/8), SURVEY.md F8."""
+
+    def __init__(self, num_layers, cin, bn_size):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module("denselayer%d" % (i + 1), _DenseLayerParams(cin + i * GROWTH, bn_size))
+
+
+class _TransitionParams(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(cin)
+        self.conv = nn.Conv2d(cin, cout, kernel_size=1, stride=1, bias=False)
+
+
+def _make_encoder_():
+    """RDM_Net.py:493-532."""
+    encoder = nn.Module()
+    encoder.conv_e1 = nn.Conv2d(in_channels=3, kernel_size=7, stride=2, out_channels=96, padding=3)
+    encoder.dense_e2 = _DenseBlockParams(6, 96, 57)
+    encoder.trans_e2 = _TransitionParams(384, 192)
+    encoder.dense_e3 = _DenseBlockParams(12, 192, 29)
+    encoder.trans_e3 = _TransitionParams(768, 384)
+    encoder.dense_e4 = _DenseBlockParams(36, 384, 15)
+    encoder.trans_e4 = _TransitionParams(2112, 1056)
+    return encoder
+
+
+def _wsm_output_planes(decoder_id):
+    """RDM_Net.py:556-567."""
+    return {1: 2208, 6: 2208, 7: 1664, 8: 832, 9: 416, 10: 208}.get(decoder_id, 1)
+
+
+class Quantization:
+    """Lloyd tables (RDM_Net.py:397-442), resolved relative to the package instead of the CWD.
+    ``depth_ratio_008_008_quant`` is missing upstream and DERIVED as 016**2."""
+
+    def __init__(self):
+        for s in ("016", "032", "064", "128"):
+            m = scipy.io.loadmat(os.path.join(_DATA, f"depth_ratio_{s}_{s}_quant.mat"))
+            setattr(self, f"depth_ratio_{s}_{s}_quant", m[f"depth_ratio_{s}_{s}_quant"])
+            setattr(self, f"depth_ratio_{s}_{s}_quant_inv", m[f"depth_ratio_{s}_{s}_quant_inv"])
+        self.depth_ratio_008_008_quant = self.depth_ratio_016_016_quant ** 2          # derived, not upstream
+        self.depth_ratio_008_008_quant_inv = self.depth_ratio_016_016_quant_inv ** 2
+        self._dev = {}
+
+    def get_with_id(self, id):
+        s = {3: "008", 4: "016", 5: "032", 6: "064", 7: "128"}[id]
+        return getattr(self, f"depth_ratio_{s}_{s}_quant"), getattr(self, f"depth_ratio_{s}_{s}_quant_inv")
+
+    def get_size_id(self, id):
+        return {3: 8, 4: 16, 5: 32, 6: 64, 7: 128}[id]
+
+    def device_tables(self, id, device):
+        key = (id, str(device))
+        if key not in self._dev:
+            q, inv = self.get_with_id(id)
+            self._dev[key] = (torch.from_numpy(np.ascontiguousarray(q[:, 0])).to(device), torch.from_numpy(np.ascontiguousarray(inv[:, 0])).to(device))
+        return self._dev[key]
+
+
+class Ordinal_Layer(nn.Module):
+    """RDM_Net.py:237-396.  DORN=True: ordinal regression head; DORN=False: the relative decoders
+    (ratio grid -> Lloyd -> rank-1 ALS), dormant in the reference graph, live here as operators."""
+
+    def __init__(self, decoder_id, DORN, quantizer):
+        super().__init__()
+        self.quant = quantizer
+        self.id = decoder_id - 3
+        self.dorn = DORN
+
+    def DornOrdinalRegression(self, x):
+        return cp.dorn_ordinal_regression(x)
+
+    def sparse_comparison_v1(self, d_3):
+        q, inv = self.quant.device_tables(3, d_3.device)
+        return cp.ratio_grid_lloyd_dense(d_3, q, inv)
+
+    def sparse_comparison_id(self, dn, dn_1):
+        q, inv = self.quant.device_tables(self.id, dn.device)
+        return cp.ratio_grid_lloyd_paged(dn, dn_1, q, inv)[0]
+
+    def forward(self, x):
+        if self.dorn:
+            return self.DornOrdinalRegression(x)
+        if self.id == 3:                                                     # d_6
+            return cp.quadratic_als(self.sparse_comparison_v1(x), cuda=x.is_cuda, n=3)
+        dn = x
+        dn_1 = cp.resize(dn, self.quant.get_size_id(self.id - 1))
+        q, inv = self.quant.device_tables(self.id, dn.device)
+        R = cp.ratio_grid_lloyd_paged(dn, dn_1, q, inv)                      # (P,B,256,64) f64
+        pages = cp.als_pages(R, limit=100)                                   # (P,B,1,16,16) f32
+        if self.id == 4:                                                     # d_7: single page
+            return pages[0]
+        return cp.reconstruct(list(pages))                                   # d_8..d_10
+
+
+class Decoder(nn.Module):
+    """RDM_Net.py:137-162 (id 1 is the only decoder the reference instantiates)."""
+
+    def __init__(self, in_channels, num_wsm_layers, DORN, id, quant):
+        super().__init__()
+        assert 0 <= num_wsm_layers < 5
+        if num_wsm_layers != 0:
+            raise NotImplementedError("WSM decoder blocks are provided as standalone operators (md_rdm_amd.network.wsm)")
+        self.id = id
+        self.dense_layer = _DenseBlockParams(24, 1056, 8)
+        self.wsm_block = nn.Sequential()
+        self.conv1 = nn.Conv2d(in_channels=_wsm_output_planes(id), out_channels=1, kernel_size=1)
+        self.conv2 = nn.Conv2d(in_channels=_wsm_output_planes(id), out_channels=180, kernel_size=1)
+        self.ord_layer = Ordinal_Layer(id, DORN, quant)
+
+
+class Weights(nn.Module):
+    """RDM_Net.py:443-491: one weight vector per pyramid level, |randn| initialised."""
+
+    def __init__(self, vector_sizes, use_cuda, relative_only):
+        super().__init__()
+        self.use_cuda = use_cuda
+        self.relative_only = relative_only
+        for n, s in zip(["d0", "f1", "f2", "f3", "f4", "f5", "f6", "f7"], vector_sizes):
+            setattr(self, n, nn.Parameter(torch.abs(torch.randn((s, 1)))))
+        self.weight_list = [self.d0, self.f1, self.f2, self.f3, self.f4, self.f5, self.f6, self.f7]
+        for w in self.weight_list:
+            if w.shape[0] == 0:
+                w.requires_grad = False
+
+    def get(self, index):
+        return self.weight_list[index]
+
+    def forward(self, x):
+        return cp.make_pred(self.weight_list, x, self.use_cuda, self.relative_only)
+
+
+# ------------------------------------------------------------------------------------------
+# the conv stack as one autograd node over the native plan
+# ------------------------------------------------------------------------------------------
+class _ConvStackFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        logits = model._native_forward(x)
+        ctx.model = model
+        ctx.gen = model._ws_generation
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if ctx.gen != model._ws_generation:
+            raise _lib.RdmError("the saved activations were overwritten by a later forward() of the same model "
+                                "(one in-flight training step per model instance)")
+        grads = model._native_backward(dlogits.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class DepthEstimationNet(BaseModel):
+    """Drop-in for the reference class (RDM_Net.py:25-135)."""
+
+    def __init__(self):
+        super().__init__()
+        self.quantizers = Quantization()
+        self.encoder = _make_encoder_()
+        if freeze_encoder:
+            self.freeze_encoder()
+        self.d_1 = Decoder(in_channels=1056, num_wsm_layers=0, DORN=True, id=1, quant=self.quantizers)
+        self.weight_layer = Weights(vector_sizes=[1, 1, 1, 1, 0, 0, 0, 0], use_cuda=use_cuda, relative_only=False)
+        # native-plan state (not part of the state_dict)
+        self._plans = {}
+        self._ws = None
+        self._ws_generation = 0
+        self._flat = None          # (flat_params, flat_grads, [(name, tensor, offset, numel)])
+        self._names = None
+        self.direct_grads = False  # True: backward writes straight into the flat gradient buffer (fast path of our harness)
+        self.grad_ready_hook = None  # callable(segment, first_param, last_param) fired after each backward segment (DP overlap)
+
+    def freeze_encoder(self):
+        for parameter in self.encoder.parameters():
+            parameter.requires_grad = False
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _tensor_table(self):
+        """state_dict tensors in the registry order of the native plan (== reference order)."""
+        L = _lib.lib()
+        if self._names is None:
+            n = L.rdm_net_num_tensors()
+            self._names = [L.rdm_net_tensor_name(i).decode() for i in range(n)]
+            self._is_param = [bool(L.rdm_net_tensor_is_param(i)) for i in range(n)]
+        named = dict(self.named_parameters())
+        named.update(dict(self.named_buffers()))
+        return [named[k] for k in self._names]
+
+    def stack_parameters(self):
+        """Float parameters of the conv stack, in plan order (everything except weight_layer.*)."""
+        tensors = self._tensor_table()
+        return [(k, t) for k, t, p in zip(self._names, tensors, self._is_param) if p and not k.startswith("weight_layer.")]
+
+    def flatten_parameters(self):
+        """Re-home every conv-stack parameter into ONE contiguous buffer (and a twin gradient
+        buffer) so the optimiser and the gradient all-reduce are single flat operations.
+        Parameter objects keep their identity; only ``.data`` is re-pointed."""
+        ps = self.stack_parameters()
+        dev = ps[0][1].device
+        offs, off = [], 0
+        for _, p in ps:
+            offs.append(off)
+            off += (p.numel() + 63) // 64 * 64          # 256-byte alignment of every tensor
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        entries = []
+        for (k, p), o in zip(ps, offs):
+            n = p.numel()
+            flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + n].view(p.shape)
+            entries.append((k, p, o, n, gflat[o:o + n].view(p.shape)))
+        self._flat = (flat, gflat, entries)
+        return flat, gflat
+
+    def _ensure_flat(self, device):
+        if self._flat is None or self._flat[0].device != device or self._flat[2][0][1].data_ptr() != self._flat[0].data_ptr():
+            self.flatten_parameters()
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._plans:
+            L = _lib.lib()
+            h = C.c_void_p()
+            _lib.check(L.rdm_net_create(B, H, W, C.byref(h)))
+            oh, ow = C.c_int32(), C.c_int32()
+            _lib.check(L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)))
+            self._plans[key] = (h, int(L.rdm_net_workspace_bytes(h)), oh.value, ow.value)
+        return self._plans[key]
+
+    def _native_forward(self, x):
+        if not x.is_cuda:
+            raise _lib.RdmError("DepthEstimationNet runs on the MI355X only (input is on %s); there is no CPU fallback" % x.device)
+        L = _lib.lib()
+        x = x.contiguous().float()
+        B, Cin, H, W = x.shape
+        assert Cin == 3
+        self._ensure_flat(x.device)
+        h, ws_bytes, oh, ow = self._plan(B, H, W)
+        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != x.device:
+            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        tensors = self._tensor_table()
+        table = (C.c_void_p * len(tensors))(*[t.data_ptr() if t.numel() else None for t in tensors])
+        logits = torch.empty(B, 180, oh, ow, dtype=torch.float32, device=x.device)
+        self._ws_generation += 1
+        _lib.check(L.rdm_net_forward(h, _lib.ptr(x), table, C.c_void_p(self._ws.data_ptr()), ws_bytes, _lib.ptr(logits), int(self.training), _lib.stream()))
+        self._last = (h, ws_bytes, table, tensors)
+        return logits
+
+    def _native_backward(self, dlogits):
+        L = _lib.lib()
+        h, ws_bytes, table, tensors = self._last
+        flat, gflat, entries = self._flat
+        gview = {k: g for k, p, o, n, g in entries}
+        want = {k: p.requires_grad for k, p, o, n, g in entries}
+        gt = []
+        for k, t, is_p in zip(self._names, tensors, self._is_param):
+            g = gview.get(k) if (is_p and want.get(k, False)) else None
+            gt.append(g.data_ptr() if g is not None else None)
+        gtable = (C.c_void_p * len(gt))(*gt)
+        st = _lib.stream()
+        for seg in range(4):
+            _lib.check(L.rdm_net_backward(h, _lib.ptr(dlogits), table, gtable, C.c_void_p(self._ws.data_ptr()), ws_bytes, seg, seg, st))
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(seg)
+        out = []
+        for k, p, o, n, g in entries:
+            if not p.requires_grad or k.startswith("d_1.conv1."):
+                out.append(None)                      # d_1.conv1 is unused for id 1 (RDM_Net.py:156-157)
+            elif self.direct_grads:
+                p.grad = g
+                out.append(None)
+            else:
+                out.append(g)
+        return out
+
+    def debug_buffer(self, name):
+        """Float view of a named internal buffer of the last forward's plan (tests / debugging)."""
+        h = self._last[0]
+        off, n = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().rdm_net_buffer(h, name.encode(), C.byref(off), C.byref(n)))
+        return self._ws[off.value:off.value + 4 * n.value].view(torch.float32)
+
+    def segment_slices(self):
+        """[(start, stop)] element ranges of the flat gradient buffer produced by backward segments 0..3."""
+        L = _lib.lib()
+        flat, gflat, entries = self._flat
+        pos = {k: (o, o + n) for k, p, o, n, g in entries}
+        res = []
+        for seg in range(4):
+            a, b = C.c_int32(), C.c_int32()
+            _lib.check(L.rdm_net_segment_range(seg, C.byref(a), C.byref(b)))
+            ks = [self._names[i] for i in range(a.value, b.value + 1) if self._names[i] in pos]
+            res.append((min(pos[k][0] for k in ks), max(pos[k][1] for k in ks)))
+        return res
+
+    # ---- the reference forward (RDM_Net.py:70-135) -----------------------------------------
+    def forward(self, x):
+        params = [p for _, p in self.stack_parameters()] if self._flat is None else [p for _, p, _, _, _ in self._flat[2]]
+        logits = _ConvStackFunction.apply(self, x, *params)                    # encoder + d_1 up to conv2
+        x_d1, ord_labels = self.d_1.ord_layer(logits)                           # DORN head, :347-357
+        B, _, H, W = x_d1.size()
+        # geometric-mean normalisation of the count map (:117); documented generalisation for
+        # non-square encoder outputs (the reference raises there): exponent 1/(H*W) and a bicubic
+        # resize to the largest power-of-two square before decomposition
+        norm = cp.gm_normalize(x_d1, 1.0 / (H * W)).float()
+        side = 2 ** int(math.floor(math.log2(min(H, W))))
+        if (H, W) != (side, side):
+            norm = cp.resize(norm, side)
+        f_d1 = cp.decompose_depth_map([], norm, int(math.log2(side)))[::-1]     # :117
+        y_hat = cp.relative_fine_detail_matrix([f_d1], use_cuda)                # :126
+        y_hat = self.weight_layer(y_hat)                                        # :133
+        return y_hat, x_d1, ord_labels
