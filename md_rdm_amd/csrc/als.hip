@@ -144,6 +144,7 @@ __global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, floa
     const float etot = block_sum_f<ROWS>(e, red);
     if (t == 0) S[(long)it * batch] = (double)etot;
     if (it == limit) break;
+    if (it == 0) continue;       // record 0 is the all-ones start; the first q-update follows the first p-update
     // q-update: thread t owns row t of R == flat elements [t*64, t*64+64) == R'[t/Q][(t%Q)*64 ...]
     p[t] = pi;
     const float pp = block_sum_f<ROWS>(pi * pi, red);      // also orders the p[] writes before the reads below

@@ -1,0 +1,114 @@
+"""C-ABI boundary: every symbol include/rdm_hip.h declares is exported and bound; argument errors
+come back as status codes + messages (no aborts); the product never imports the oracle.  CPU only
+(no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+HEADER = os.path.join(ROOT, "include", "rdm_hip.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from md_rdm_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_header_symbols_exported_and_bound(L):
+    from md_rdm_amd import _lib
+    hdr = open(HEADER).read()
+    declared = set(re.findall(r"\b(rdm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    bound = set(_lib.exported_symbols())
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_every_entry_point_cites_the_reference():
+    hdr = open(HEADER).read()
+    assert hdr.count("RDM_Net.py:") >= 6 and hdr.count("computations.py:") >= 8
+    assert "loss.py:8-59" in hdr and "utils.py:195-211" in hdr and "module.py:41" in hdr
+
+
+def test_registry_matches_reference_state_dict(L):
+    want = [l.split(" ", 1) for l in open(os.path.join(GOLDEN, "state_dict_keys.txt")).read().splitlines()]
+    assert L.rdm_net_num_tensors() == len(want) == 968
+    total = 0
+    for i, (k, rest) in enumerate(want):
+        assert L.rdm_net_tensor_name(i).decode() == k
+        shape = eval(rest.rsplit(" ", 1)[0])
+        n = 1
+        for s in shape:
+            n *= s
+        assert L.rdm_net_tensor_numel(i) == n, k
+        is_param = "running" not in k and "num_batches" not in k
+        assert bool(L.rdm_net_tensor_is_param(i)) == is_param
+        total += n if is_param else 0
+    assert total == 90529721
+
+
+def test_plan_geometry_and_flops(L):
+    h = C.c_void_p()
+    assert L.rdm_net_create(16, 228, 304, C.byref(h)) == 0
+    oh, ow = C.c_int32(), C.c_int32()
+    assert L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (8, 10)
+    assert 4 * 2**30 < L.rdm_net_workspace_bytes(h) < 16 * 2**30
+    # 155.7 GFLOP/img forward, 466.5 GFLOP/img per train step at 228x304
+    f, b = L.rdm_net_forward_flops(h) / 16 / 1e9, L.rdm_net_backward_flops(h) / 16 / 1e9
+    assert abs(f - 155.7) < 0.3 and abs(f + b - 466.5) < 1.0
+    L.rdm_net_destroy(h)
+    assert L.rdm_net_create(1, 228, 228, C.byref(h)) == 0
+    assert abs(L.rdm_net_forward_flops(h) / 1e9 - 118.4) < 0.3
+    assert L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)) == 0 and (oh.value, ow.value) == (8, 8)
+    L.rdm_net_destroy(h)
+
+
+def test_errors_are_status_codes(L):
+    h = C.c_void_p()
+    assert L.rdm_net_create(0, 228, 228, C.byref(h)) == -1
+    assert b"batch" in L.rdm_last_error_string()
+    assert L.rdm_net_create(1, 8, 8, C.byref(h)) == -1
+    assert L.rdm_dorn_fwd(None, None, None, 1, 90, 64, None) == -1
+    assert L.rdm_als_rank1(None, 0, None, 1, 1, 100, 64, 30, None, 0, None) == -1
+    from md_rdm_amd._lib import ConvDesc
+    d = ConvDesc(1, 8, 8, 20, 20, 16, 16, 3, 3, 1, 1, 1, 1)
+    assert L.rdm_conv2d_fwd(C.byref(d), C.c_void_p(256), C.c_void_p(256), None, None, None, C.c_void_p(256), None, None, None) == -1
+    assert b"multiple of 16" in L.rdm_last_error_string()
+    a, b = C.c_int32(), C.c_int32()
+    assert L.rdm_net_segment_range(7, C.byref(a), C.byref(b)) == -1
+    assert L.rdm_net_segment_range(0, C.byref(a), C.byref(b)) == 0 and L.rdm_net_tensor_name(b.value).decode() == "d_1.conv2.bias"
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "md_rdm_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "/root/reference" not in txt or f.endswith(".py") and "reference" in txt, f
+
+
+def test_model_surface_on_cpu():
+    """Construction, state_dict keys/shapes/dtypes and the loud failure without a GPU."""
+    import torch
+    from md_rdm_amd.network import RDM_Net
+    from md_rdm_amd import _lib
+    m = RDM_Net.DepthEstimationNet()
+    sd = m.state_dict()
+    want = [l.split(" ", 1) for l in open(os.path.join(GOLDEN, "state_dict_keys.txt")).read().splitlines()]
+    assert list(sd.keys()) == [k for k, _ in want]
+    for (k, rest), v in zip(want, sd.values()):
+        assert rest == f"{tuple(v.shape)} {str(v.dtype).replace('torch.', '')}", k
+    assert sum(p.numel() for p in m.parameters()) == 90529721
+    assert RDM_Net.use_cuda is True and RDM_Net.freeze_encoder is False
+    m.freeze_encoder()
+    assert not any(p.requires_grad for p in m.encoder.parameters())
+    with pytest.raises(_lib.RdmError):
+        m(torch.zeros(1, 3, 228, 228))          # no CPU fallback

@@ -1,0 +1,245 @@
+"""-m gpu: post-processing / head / relative-decoder kernels through the C ABI vs the oracle and the
+reference-generated goldens.  Bit-exact for integer outputs (ordinal counts, SID labels, Lloyd
+levels); float tolerances are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from md_rdm_amd import filler
+from oracle import computations_cpu as ocp
+
+pytestmark = pytest.mark.gpu
+U, LU = filler.uniform, filler.log_uniform
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from md_rdm_amd import loss, utils
+    from md_rdm_amd.network import RDM_Net, computations as cp
+    return dict(cp=cp, RDM=RDM_Net, loss=loss, utils=utils, dev=torch.device("cuda:0"))
+
+
+def g(a, env):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(env["dev"])
+
+
+def test_native_library_is_loaded(env):
+    from md_rdm_amd import _lib
+    _lib.lib()
+    assert any("librdm_hip.so" in l for l in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("h,w,s", [(8, 8, 4), (2, 2, 1), (8, 8, 8), (226, 226, 128), (128, 128, 64), (8, 10, 8), (228, 304, 128), (128, 128, 8), (11, 38, 8)])
+def test_resize(env, op_gold, h, w, s):
+    src = LU(f"op.rs{h}x{w}", (2, 1, h, w), 0.5, 9.5)
+    got = env["cp"].resize(g(src, env), s)
+    assert got.dtype == torch.float64
+    np.testing.assert_allclose(got.cpu().numpy(), op_gold[f"resize_{h}x{w}_to_{s}"], rtol=1e-12, atol=1e-13)
+
+
+def test_quick_gm_and_normalize(env, op_gold):
+    cp = env["cp"]
+    d = LU("op.gm", (3, 64, 1), 0.5, 2.0)
+    np.testing.assert_allclose(cp.quick_gm(g(d, env), 8).cpu().numpy(), op_gold["quick_gm_8"], rtol=1e-5)   # reference: 64 f32 roundings
+    di = np.floor(U("op.gmi", (3, 64, 1), 1, 60)).astype(np.int64)
+    got = cp.quick_gm(g(di, env), 8)
+    assert got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), ocp.quick_gm(di, 8), rtol=2e-7)
+    x = LU("n", (2, 1, 8, 8), 0.5, 9.0).astype(np.float64)
+    want = x / ocp.quick_gm(x.reshape(2, 64, 1), 8).reshape(2, 1, 1, 1)
+    np.testing.assert_allclose(cp.gm_normalize(g(x, env), 1 / 64).cpu().numpy(), want, rtol=1e-13)
+
+
+def test_decompose_pred_recombine(env, op_gold):
+    cp = env["cp"]
+    src = LU("op.dec8", (2, 1, 8, 8), 0.5, 2.0).astype(np.float64)
+    comps = cp.decompose_depth_map([], g(src, env), 3)[::-1]
+    for i, t in enumerate(comps):
+        np.testing.assert_allclose(t.cpu().numpy(), op_gold[f"decompose3_{i}"], rtol=1e-12)
+    src = LU("op.dec128", (2, 1, 128, 128), 0.5, 9.5)
+    comps = cp.decompose_depth_map([], g(src, env), 7)[::-1]
+    assert [c.shape[2] for c in comps] == [1, 2, 4, 8, 16, 32, 64, 128]
+    np.testing.assert_allclose(comps[0].cpu().numpy(), op_gold["decompose7_0"], rtol=1e-11)
+    np.testing.assert_allclose(comps[3].cpu().numpy(), op_gold["decompose7_3"], rtol=1e-11)
+    np.testing.assert_allclose(comps[7][:, :, :6, :6].cpu().numpy(), op_gold["decompose7_7_corner"], rtol=1e-11)
+    rel = cp.decompose_depth_map([], g(LU("op.decrel", (2, 1, 16, 16), 0.5, 2.0).astype(np.float64), env), 4, relative_map=True)[::-1]
+    assert len(rel) == int(op_gold["decompose4_rel_len"])
+    np.testing.assert_allclose(rel[0].cpu().numpy(), op_gold["decompose4_rel_0"], rtol=1e-12)
+    # live graph: one candidate row -> fused log*w, then recombination (+ gradients of the 4 scalars)
+    src = LU("live", (3, 1, 8, 8), 0.5, 2.0).astype(np.float64)
+    w = [torch.nn.Parameter(g(U(f"w{i}", (1, 1), 0.5, 1.5), env)) for i in range(4)]
+    rows = cp.decompose_depth_map([], g(src, env), 3)[::-1]
+    yh = cp.make_pred(w + [None] * 4, cp.relative_fine_detail_matrix([rows], True), True, False)
+    o_comps = ocp.decompose_depth_map(src, 3)[::-1]
+    o_yh = ocp.make_pred([p.detach().cpu().numpy() for p in w], ocp.relative_fine_detail_matrix([o_comps]))
+    for a, b in zip(yh, o_yh):
+        assert a.dtype == torch.float32
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b, rtol=1e-6, atol=1e-8)
+    final = cp.recombination(list(yh), 7)
+    np.testing.assert_allclose(final.detach().cpu().numpy(), ocp.recombination(o_yh, 7), rtol=1e-12, atol=1e-14)
+    tgt = g(U("tgt", (3, 1, 128, 128), -1, 1).astype(np.float64), env)
+    ((final - tgt) ** 2).mean().backward()
+    logs = [np.log(c).astype(np.float32).astype(np.float64) for c in o_comps]
+    fin = ocp.recombination(o_yh, 7)
+    for k in range(4):
+        up = ocp.multi_upsample(logs[k], 7 - k)
+        want = (2 * (fin - tgt.cpu().numpy()) * up).mean()
+        assert abs(w[k].grad.item() - want) <= 1e-5 * abs(want) + 1e-9
+
+
+def test_general_multi_candidate_path(env, op_gold):
+    cp = env["cp"]
+    f1 = [g(LU(f"op.fd1_{i}", (2, 1, 2 ** i, 2 ** i), 0.5, 2.0).astype(np.float64), env) for i in range(4)]
+    f2 = [g(LU(f"op.fd2_{i}", (2, 1, 2 ** i, 2 ** i), 0.5, 2.0).astype(np.float64), env) for i in range(1, 4)]
+    mats = cp.relative_fine_detail_matrix([f1, f2], True)
+    for i, m in enumerate(mats):
+        np.testing.assert_allclose(m.cpu().numpy(), op_gold[f"rfdm_{i}"], rtol=1e-13, atol=1e-15)
+    w = [g(U("op.w0", (1, 1), 0.5, 1.5), env)] + [g(U(f"op.w{i}", (2, 1), 0.2, 0.8), env) for i in (1, 2, 3)]
+    for i, p in enumerate(cp.make_pred(w, mats, True, False)):
+        np.testing.assert_allclose(p.cpu().numpy(), op_gold[f"make_pred_{i}"], rtol=1e-5, atol=1e-6)
+    comps = [g(U(f"op.rc{i}", (2, 1, 2 ** i, 2 ** i), -1.0, 1.0).astype(np.float64), env) for i in range(4)]
+    np.testing.assert_allclose(cp.recombination(list(comps), 3).cpu().numpy(), op_gold["recombination_n3"], rtol=1e-14)
+    np.testing.assert_allclose(cp.recombination(list(comps[1:]), 4).cpu().numpy(), op_gold["recombination_n4_rel"], rtol=1e-14)
+
+
+def test_sid_labels_bit_exact(env, op_gold):
+    dep = np.concatenate([LU("op.sid", (60,), 0.005, 12.0), np.array([1e-4, 0.02, 10.0, 0.0199999], dtype=np.float32)]).reshape(1, 1, 8, 8).astype(np.float64)
+    got = env["utils"].depth2label_sid(g(dep, env), cuda=True)
+    assert got.dtype == torch.int32
+    np.testing.assert_array_equal(got.cpu().numpy(), op_gold["depth2label_sid"])
+    big = LU("sid.big", (16, 1, 128, 128), 0.01, 12.0).astype(np.float64)          # full-size property: equals the oracle everywhere
+    np.testing.assert_array_equal(env["utils"].depth2label_sid(g(big, env)).cpu().numpy(), ocp.depth2label_sid(big))
+
+
+def test_dorn_head_and_backward(env, op_gold):
+    xl = U("op.dorn", (2, 180, 8, 10), -2.0, 3.0)
+    xl.flat[::53] = 2e4
+    xl.flat[7::59] = -5.0
+    xl[0, 10, 0, 0] = xl[0, 11, 0, 0]
+    xt = g(xl, env).requires_grad_(True)
+    dec, lab = env["RDM"].Ordinal_Layer(1, True, None)(xt)
+    assert dec.dtype == torch.int64 and lab.dtype == torch.float64 and dec.shape == (2, 1, 8, 10)
+    np.testing.assert_array_equal(dec.cpu().numpy(), op_gold["dorn_decode"])                      # bit-exact ordinal indices
+    np.testing.assert_allclose(lab.detach().cpu().numpy(), op_gold["dorn_labels"], rtol=1e-14, atol=1e-300)
+    (lab * g(U("op.dorn_g", (2, 90, 8, 10), -1, 1).astype(np.float64), env)).sum().backward()
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), op_gold["dorn_dx"], rtol=1e-6, atol=1e-9)
+    # full-size property: count == #{clamp(b) > clamp(a)} for a large random tensor
+    big = U("dorn.big", (16, 180, 8, 10), -3, 3)
+    d2, _ = env["cp"].dorn_ordinal_regression(g(big, env))
+    np.testing.assert_array_equal(d2.cpu().numpy(), ocp.dorn_ordinal_regression(big)[0])
+
+
+def test_ordinal_loss(env, op_gold):
+    P = U("op.ol_p", (2, 90, 8, 8), 0.0, 1.0).astype(np.float64)
+    P.flat[::97] = 0.0
+    P.flat[5::101] = 1.0
+    T = np.floor(U("op.ol_t", (2, 1, 8, 8), 0, 95)).astype(np.int32)
+    Pt = g(P, env).requires_grad_(True)
+    lo = env["loss"].Ordinal_Loss().calc(Pt, g(T, env), cuda=True)
+    assert abs(lo.item() - float(op_gold["ordinal_loss"])) < 2e-6 * abs(float(op_gold["ordinal_loss"]))
+    lo.backward()
+    np.testing.assert_allclose(Pt.grad.cpu().numpy(), op_gold["ordinal_loss_dP"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("oid,s", [(7, "016"), (8, "032"), (9, "064"), (10, "128")])
+def test_lloyd_bit_exact_via_paged_grid(env, op_gold, oid, s):
+    """Feed values sitting exactly on / one ulp below every threshold through the quantiser."""
+    cp, RDM = env["cp"], env["RDM"]
+    quant = RDM.Quantization()
+    q, inv = quant.get_with_id(oid - 3)
+    rr = LU(f"op.lloyd{s}", (1, 32, 16), 0.2, 5.0).astype(np.float64)
+    rr.flat[:40] = q[:, 0]
+    rr.flat[40:80] = np.nextafter(q[:, 0], 0)
+    want = op_gold[f"lloyd_{s}"].reshape(-1)
+    # the paged grid with coarse map == 1 everywhere yields R[b,fine,:] = dn[fine]: use f32-exact probes only
+    vals = rr.reshape(-1)
+    exact32 = vals.astype(np.float32).astype(np.float64) == vals
+    dn = np.ones((2, 1, 16, 16), dtype=np.float32)
+    probes = vals[exact32][:256]
+    dn.reshape(2, 256)[0, :len(probes)] = probes.astype(np.float32)
+    qd, invd = quant.device_tables(oid - 3, env["dev"])
+    R = cp.ratio_grid_lloyd_paged(g(dn, env), torch.ones(2, 1, 8, 8, dtype=torch.float64, device=env["dev"]), qd, invd)
+    np.testing.assert_array_equal(R[0, 0, :len(probes), 0].cpu().numpy(), want[exact32][:len(probes)])
+    # and the oracle agrees on the full probe set (thresholds included)
+    np.testing.assert_array_equal(ocp.lloyd_quantization(rr, q[:, 0], inv[:, 0])[0].reshape(-1), want)
+
+
+def test_ratio_grids(env, op_gold):
+    cp, RDM = env["cp"], env["RDM"]
+    quant = RDM.Quantization()
+    d3 = LU("op.d3", (2, 1, 8, 8), 0.5, 2.0)
+    o6 = RDM.Ordinal_Layer(6, False, quant)
+    np.testing.assert_array_equal(o6.sparse_comparison_v1(g(d3, env)).cpu().numpy(), op_gold["derived008_sparse_v1"])   # derived 008 table
+    dn = LU("op.dn16", (2, 1, 16, 16), 0.5, 2.0)
+    dn1 = cp.resize(g(dn, env), 8)
+    qd, invd = quant.device_tables(4, env["dev"])
+    raw = cp.ratio_grid_lloyd_paged(g(dn, env), dn1, qd, invd, quantize=False)[0]
+    np.testing.assert_allclose(raw.cpu().numpy(), op_gold["ratio_grid_raw_16"], rtol=1e-15)
+    o7 = RDM.Ordinal_Layer(7, False, quant)
+    R = o7.sparse_comparison_id(g(dn, env), dn1)
+    assert R.dtype == torch.float64
+    got, want = R.cpu().numpy(), op_gold["sparse_id_016"]
+    assert (got != want).mean() < 1e-4        # bit-exact except grid values within 1 ulp of a threshold
+    # 4-page map: page order and window clamping
+    d32 = LU("op.d32", (2, 1, 32, 32), 0.5, 2.0)
+    d16 = cp.resize(g(d32, env), 16)
+    q5, i5 = quant.device_tables(5, env["dev"])
+    Rp = cp.ratio_grid_lloyd_paged(g(d32, env), d16, q5, i5).cpu().numpy()
+    a, b = ocp.split_matrix(d32, d16.cpu().numpy())
+    t = ocp.load_quant_tables()["032"]
+    for p in range(4):
+        want = ocp.lloyd_quantization(ocp.ratio_grid_raw(a[p], b[p]), *t)[0]
+        assert (Rp[p] != want).mean() < 1e-4
+
+
+@pytest.mark.parametrize("lim", [1, 5, 30, 100])
+def test_als_generic(env, op_gold, lim):
+    R = LU("op.alsR", (3, 256, 64), 0.5, 2.0)
+    got = env["cp"].alternating_least_squares(g(R, env), n=4, cuda=True, limit=lim)
+    assert got.shape == (3, 1, 16, 16) and got.dtype == torch.float32
+    # 3e-5: the reference's own float32 quick_gm with exponent 1/65536 (256 pow roundings)
+    np.testing.assert_allclose(got.cpu().numpy(), op_gold[f"als_generic_limit{lim}"], rtol=3e-5)
+
+
+def test_als_quadratic_and_decoders(env, op_gold):
+    cp, RDM = env["cp"], env["RDM"]
+    R8 = LU("op.alsR8", (2, 64, 64), 0.5, 2.0)
+    np.testing.assert_allclose(cp.quadratic_als(g(R8, env), cuda=True, n=3).cpu().numpy(), op_gold["quadratic_als_generic"], rtol=3e-5)
+    quant = RDM.Quantization()
+    d3 = LU("op.d3", (2, 1, 8, 8), 0.5, 2.0)
+    np.testing.assert_allclose(RDM.Ordinal_Layer(6, False, quant)(g(d3, env)).cpu().numpy(), op_gold["derived008_d6_forward"], rtol=3e-5)
+    dn = LU("op.dn16", (2, 1, 16, 16), 0.5, 2.0)
+    np.testing.assert_allclose(RDM.Ordinal_Layer(7, False, quant)(g(dn, env)).cpu().numpy(), op_gold["d7_forward"], rtol=3e-5)
+    d32 = LU("op.d32", (2, 1, 32, 32), 0.5, 2.0)
+    np.testing.assert_allclose(RDM.Ordinal_Layer(8, False, quant)(g(d32, env)).cpu().numpy(), op_gold["d8_forward"], rtol=3e-5)
+
+
+def test_paging(env, op_gold):
+    cp = env["cp"]
+    d32 = LU("op.d32", (2, 1, 32, 32), 0.5, 2.0)
+    d16 = cp.resize(g(d32, env), 16)
+    a, b = cp.split_matrix(g(d32, env), d16)
+    assert len(a) == int(op_gold["split_len"])
+    np.testing.assert_array_equal(a[2].cpu().numpy(), op_gold["split_first_2"])
+    np.testing.assert_allclose(b[3].cpu().numpy(), op_gold["split_second_3"], rtol=1e-6)
+    pages = [g(U(f"op.pg{i}", (2, 1, 16, 16), 0, 1), env) for i in range(4)]
+    np.testing.assert_array_equal(cp.reconstruct(pages).cpu().numpy(), op_gold["reconstruct_4pages"])      # bug-as-spec
+
+
+def test_als_full_size_properties(env):
+    """d_10 scale (64 pages x B=16 = 1024 matrices): rank-1 recovery and
+    exact agreement between the paged call and per-page calls (batch-global arg-min per page)."""
+    cp = env["cp"]
+    R = g(LU("als.big", (64, 16, 256, 64), 0.5, 2.0), env)
+    p = cp.als_pages(R, limit=100)
+    assert torch.isfinite(p).all()
+    one = cp.alternating_least_squares(R[5], n=4, cuda=True, limit=100)
+    assert torch.equal(one, p[5])
+    assert (p > 0).all()
+    # rank-1 consistency: for a rank-1 input u v^T the (un-normalised) first iterate is proportional to u
+    u = g(LU("als.u", (1, 16, 256, 1), 0.5, 2.0), env)
+    v = g(LU("als.v", (1, 16, 1, 64), 0.5, 2.0), env)
+    out = cp.als_pages((u * v).contiguous(), limit=100).view(16, 256)
+    ratio = out / u.view(16, 256)
+    np.testing.assert_allclose((ratio / ratio[:, :1]).cpu().numpy(), 1.0, rtol=2e-4)
