@@ -110,41 +110,51 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
   }
   const bool bnrelu = p.a_scale != nullptr;
 
-  float4 ra[AL], rb[BL];
-  auto load_slab = [&](int s) {
-    int cs = s, tap = 0, r = 0, q = 0;
-    if (TAPS) { cs = s / ntaps; tap = s - cs * ntaps; r = tap / G.KW; q = tap - r * G.KW; }
-    const int c0 = cs * BK;
+  // slab cursor: channel slab `cs` outer, filter tap (r,q) inner - advanced incrementally
+  int cur_cs = s_begin, cur_tap = 0, cur_r = 0, cur_q = 0;
+  if (TAPS) { cur_cs = s_begin / ntaps; cur_tap = s_begin - cur_cs * ntaps; cur_r = cur_tap / G.KW; cur_q = cur_tap - cur_r * G.KW; }
+  auto advance = [&]() {
+    if (TAPS) {
+      ++cur_tap; ++cur_q;
+      if (cur_q == G.KW) { cur_q = 0; ++cur_r; }
+      if (cur_tap == ntaps) { cur_tap = 0; cur_r = 0; cur_q = 0; ++cur_cs; }
+    } else {
+      ++cur_cs;
+    }
+  };
+
+  // Raw loads only: nothing below consumes a loaded value, so the loads stay in flight across the
+  // MFMA phase of the current slab; BN-ReLU / zero padding are applied when staging into LDS.
+  float4 ra[AL], rb[BL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool rok[AL];
+  const int kq_a = tid & 3;                                  // every A load of this thread has the same k-quad
+  auto load_slab = [&]() {
+    const int c0 = cur_cs * BK;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const int idx = tid + i * 256;
-      const int kq = idx & 3;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       bool ok = a_ok[i];
-      const float* src = nullptr;
+      const float* src;
       if (TAPS) {
-        const int iy = a_iy[i] + G.dir * r, ix = a_ix[i] + G.dir * q;
+        const int iy = a_iy[i] + G.dir * cur_r, ix = a_ix[i] + G.dir * cur_q;
         ok = ok && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
-        src = p.A + (a_off[i] + (long)iy * G.W + ix) * p.lda + c0 + kq * 4;
+        src = p.A + (a_off[i] + (long)iy * G.W + ix) * p.lda + c0 + kq_a * 4;
       } else {
-        src = p.A + a_off[i] + c0 + kq * 4;
+        src = p.A + a_off[i] + c0 + kq_a * 4;
       }
-      if (ok) {
-        v = ld4(src);
-        if (bnrelu) v = bnrelu4(v, ld4(p.a_scale + c0 + kq * 4), ld4(p.a_shift + c0 + kq * 4));
-      }
-      ra[i] = v;
+      rok[i] = ok;
+      ra[i] = ok ? ld4(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
       const int idx = tid + i * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!B_KSTRIDED) {
         const int row = idx >> 2, kq = idx & 3;
-        if (idx < BN * 4 && n0 + row < p.N) v = ld4(p.Wt + (long)tap * p.wtap + (long)(n0 + row) * p.ldw + c0 + kq * 4);
+        if (idx < BN * 4 && n0 + row < p.N) v = ld4(p.Wt + (long)cur_tap * p.wtap + (long)(n0 + row) * p.ldw + c0 + kq * 4);
       } else {
         const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
-        if (idx < BK * (BN / 4) && n0 + r4 * 4 < p.N) v = ld4(p.Wt + (long)tap * p.wtap + (long)(c0 + k) * p.ldw + n0 + r4 * 4);
+        if (idx < BK * (BN / 4) && n0 + r4 * 4 < p.N) v = ld4(p.Wt + (long)cur_tap * p.wtap + (long)(c0 + k) * p.ldw + n0 + r4 * 4);
       }
       rb[i] = v;
     }
@@ -154,9 +164,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
     for (int i = 0; i < AL; ++i) {
       const int idx = tid + i * 256;
       if (idx < BM * 4) {
-        const int row = idx >> 2, kq = idx & 3;
-        float* d = &As[buf][(kq * 4) * LDA + row];
-        d[0] = ra[i].x; d[LDA] = ra[i].y; d[2 * LDA] = ra[i].z; d[3 * LDA] = ra[i].w;
+        const int row = idx >> 2;
+        float4 v = ra[i];
+        if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+        float* d = &As[buf][(kq_a * 4) * LDA + row];
+        d[0] = v.x; d[LDA] = v.y; d[2 * LDA] = v.z; d[3 * LDA] = v.w;
       }
     }
 #pragma unroll
@@ -183,13 +195,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_slab(s_begin);
+  load_slab();
   store_slab(0);
   __syncthreads();
   int buf = 0;
   for (int s = s_begin; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
-    if (more) load_slab(s + 1);
+    if (more) { advance(); load_slab(); }
     mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
     if (more) store_slab(buf ^ 1);
     __syncthreads();
@@ -277,7 +289,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     if (bnrelu && idx < BK * (BN / 4) && c0 + r4 * 4 < p.C) { bsc[i] = ld4(p.x_scale + c0 + r4 * 4); bsh[i] = ld4(p.x_shift + c0 + r4 * 4); }
   }
 
+  // per-thread pixel cursors of the B loads (k index is fixed per thread; the pixel advances by BK
+  // every slab) - incremental (b, oy, ox) instead of two integer divisions per load per slab
+  int pb_[BL], poy[BL], pox[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int idx = tid + i * 256;
+    const int k = idx / (BN / 4);
+    const int m = s_begin * BK + k;
+    pb_[i] = 0; poy[i] = 0; pox[i] = m;
+    if (TAPS) {
+      const int hw = G.Ho * G.Wo;
+      pb_[i] = m / hw;
+      const int rem = m - pb_[i] * hw;
+      poy[i] = rem / G.Wo; pox[i] = rem - poy[i] * G.Wo;
+    }
+  }
   float4 ra[AL], rb[BL];
+  bool rok[BL];
   auto load_slab = [&](int s) {
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -293,22 +322,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       const int idx = tid + i * 256;
       const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
       const int m = s * BK + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       bool ok = idx < BK * (BN / 4) && m < Mpix && c0 + r4 * 4 < p.C;
       long pix = m;
-      if (TAPS && ok) {
-        const int hw = G.Ho * G.Wo;
-        const int b = m / hw, rem = m - b * hw;
-        const int oy = rem / G.Wo, ox = rem - oy * G.Wo;
-        const int iy = oy * G.SH - G.PH + tr, ix = ox * G.SW - G.PW + tq;
-        ok = iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
-        pix = ((long)b * G.H + iy) * G.W + ix;
+      if (TAPS) {
+        const int iy = poy[i] * G.SH - G.PH + tr, ix = pox[i] * G.SW - G.PW + tq;
+        ok = ok && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
+        pix = ((long)pb_[i] * G.H + iy) * G.W + ix;
+        // advance this thread's pixel cursor by one slab (BK output pixels)
+        pox[i] += BK;
+        while (pox[i] >= G.Wo) { pox[i] -= G.Wo; ++poy[i]; }
+        while (poy[i] >= G.Ho) { poy[i] -= G.Ho; ++pb_[i]; }
       }
-      if (ok) {
-        v = ld4(p.Xs + pix * p.ldx + c0 + r4 * 4);
-        if (bnrelu) v = bnrelu4(v, bsc[i], bsh[i]);
-      }
-      rb[i] = v;
+      rok[i] = ok;
+      rb[i] = ok ? ld4(p.Xs + pix * p.ldx + c0 + r4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_slab = [&](int buf) {
@@ -325,7 +351,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       const int idx = tid + i * 256;
       if (idx < BK * (BN / 4)) {
         const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[buf][k * LDB + r4 * 4]) = rb[i];
+        float4 v = rb[i];
+        if (bnrelu) { v = bnrelu4(v, bsc[i], bsh[i]); if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+        *reinterpret_cast<float4*>(&Bs[buf][k * LDB + r4 * 4]) = v;
       }
     }
   };
@@ -441,12 +469,12 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   const bool taps = !(a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 &&
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const long kslabs = (long)(a.C / 16) * (taps ? a.g.KH * a.g.KW : 1);
-  // tile choice: biggest tile that still yields >= 256 workgroups, else the smallest one + split-K
-  int cfg = 2;
+  // tile choice: 128x96 when N is a multiple of 96 and the grid is large, else 256x48 (every channel
+  // count of this network is a multiple of 48); short grids are filled by split-K
   const long t0 = (long)cdiv(a.M, 256) * cdiv(a.N, 48), t1 = (long)cdiv(a.M, 128) * cdiv(a.N, 96);
-  if (a.N % 96 == 0 && t1 >= 512) cfg = 1;
-  else if (t0 >= 256) cfg = 0;
-  else if (t1 >= 256 && a.N % 96 == 0) cfg = 1;
+  int cfg = 0;
+  if (a.N % 96 == 0 && (t1 >= 512 || a.M <= 128)) cfg = 1;
+  if (a.M <= 64) cfg = 2;
   const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : (long)cdiv(a.M, 64) * cdiv(a.N, 96);
   int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs);
   if (epi == EPI_STORE_STATS || epi == EPI_MASK_STATS) split = 1;

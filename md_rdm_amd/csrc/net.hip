@@ -182,7 +182,7 @@ ConvGeom geom3x3(int B, int H, int W, int dir) { return ConvGeom{B, H, W, H, W, 
 
 // statistics of rows of a matrix are fused in the conv epilogue on big layers; split-K layers
 // (few rows) reduce with a separate pass
-inline bool fuse_stats(int M) { return M >= 8192; }
+inline bool fuse_stats(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 48) >= 256; }
 
 int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hipStream_t s) {
   const BlockGeom& g = n.bg[b];
@@ -206,7 +206,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     a.Wt = F(T, L.conv1); a.wtap = 0; a.ldw = cin;
     a.out = Y; a.ldc = g.cb; a.M = g.M; a.N = g.cb;
     a.stat0 = sty; a.stat1 = sty + g.cb;
-    const bool fuse = training && fuse_stats(g.M);
+    const bool fuse = training && fuse_stats(g.M, g.cb);
     if ((rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
     if (training && !fuse && (rc = launch_colstats(Y, g.cb, g.M, g.cb, sty, sty + g.cb, s))) return rc;
     if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
@@ -220,8 +220,9 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     c.Wt = w2p; c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
     c.out = blk + cin; c.ldc = g.ctot; c.M = g.M; c.N = GROWTH;
     c.stat0 = bst + cin; c.stat1 = bst + g.ctot + cin;
-    if ((rc = launch_conv_fwd(c, false, fuse ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
-    if (training && !fuse && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
+    const bool fuse2 = training && fuse_stats(g.M, GROWTH);
+    if ((rc = launch_conv_fwd(c, false, fuse2 ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
+    if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
   }
   return 0;
 }
@@ -249,7 +250,7 @@ int forward_transition(NetImpl& n, int t, void* ws, void* const* T, int training
   a.Wt = F(T, reg().trans_conv[t]); a.wtap = 0; a.ldw = C;
   a.out = nblk; a.ldc = gn.ctot; a.M = gn.M; a.N = Co;
   a.stat0 = nst; a.stat1 = nst + gn.ctot;
-  const bool fuse = training && fuse_stats(gn.M);
+  const bool fuse = training && fuse_stats(gn.M, Co);
   if ((rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
   if (training && !fuse && (rc = launch_colstats(nblk, gn.ctot, gn.M, Co, nst, nst + gn.ctot, s))) return rc;
   return 0;
@@ -271,7 +272,6 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
   double* s1 = at<double>(ws, n.s1);
   float* cA = at<float>(ws, n.cA); float* cB = at<float>(ws, n.cB); float* cC = at<float>(ws, n.cC);
   float* dW3 = at<float>(ws, n.dW3);
-  const bool fuse = fuse_stats(g.M);
   int rc;
   for (int i = kBlocks[b].layers - 1; i >= 0; --i) {
     const LayerIdx& L = reg().layers[b][i];
@@ -302,6 +302,7 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     d.Wt = w2p; d.wtap = (long)GROWTH * cb; d.ldw = cb;
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
+    const bool fuse = fuse_stats(g.M, cb);
     if ((rc = launch_conv_fwd(d, true, fuse ? EPI_MASK_STATS : EPI_STORE, s)) < 0) return rc;
     if (!fuse && (rc = launch_mask_stats(dZ, cb, Y, cb, bn2, bn2 + cb, g.M, cb, s0, s1, s))) return rc;
     if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, cA, cB, cC,
@@ -327,8 +328,9 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     e.Wt = F(T, L.conv1); e.wtap = 0; e.ldw = cin;
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
-    if ((rc = launch_conv_fwd(e, true, fuse ? EPI_MASK_STATS : EPI_STORE, s)) < 0) return rc;
-    if (!fuse && (rc = launch_mask_stats(dZ1, cin, blk, g.ctot, bn1, bn1 + cin, g.M, cin, s0, s1, s))) return rc;
+    const bool fuse1 = fuse_stats(g.M, cin);
+    if ((rc = launch_conv_fwd(e, true, fuse1 ? EPI_MASK_STATS : EPI_STORE, s)) < 0) return rc;
+    if (!fuse1 && (rc = launch_mask_stats(dZ1, cin, blk, g.ctot, bn1, bn1 + cin, g.M, cin, s0, s1, s))) return rc;
     if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin, cA, cB, cC,
                                    Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, cin, training, s)))
       return rc;
