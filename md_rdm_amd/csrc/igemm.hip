@@ -42,19 +42,23 @@ __device__ __forceinline__ float4 bnrelu4(float4 v, float4 sc, float4 sh) {
 template <int MT, int NT>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
                                          int wrow, int wcol, int l16, int g, f32x4 (&acc)[MT][NT]) {
+  // all fragments of the slab are fetched first (4*(MT+NT) VGPRs), so the MT*NT*4 MFMAs issue
+  // back-to-back behind ONE LDS latency instead of one per k-step
+  float a[BK / 4][MT], b[BK / 4][NT];
 #pragma unroll
   for (int ks = 0; ks < BK / 4; ++ks) {
-    float a[MT], b[NT];
     const int k = ks * 4 + g;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = As[k * lda + wrow + i * 16 + l16];
+    for (int i = 0; i < MT; ++i) a[ks][i] = As[k * lda + wrow + i * 16 + l16];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b[j] = Bs[k * ldb + wcol + j * 16 + l16];
+    for (int j = 0; j < NT; ++j) b[ks][j] = Bs[k * ldb + wcol + j * 16 + l16];
+  }
+#pragma unroll
+  for (int ks = 0; ks < BK / 4; ++ks)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-  }
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,13 +438,14 @@ int profile_read(double* ms, double* flops, int* launches) {
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
 int pick_split_k(long tiles, long kslabs) {
-  // fill 256 CUs x ~3 workgroups; keep at least 4 slabs of K per split
-  if (tiles >= 512) return 1;
-  long want = (768 + tiles - 1) / tiles;
-  long cap = kslabs / 4;
+  // 256 CUs x 3 resident workgroups = 768 slots; aim for >= 4 rounds so the last partial round
+  // costs little, but keep at least 8 slabs (128 of K) per split
+  if (tiles >= 1536) return 1;
+  long want = (3072 + tiles - 1) / tiles;
+  long cap = kslabs / 8;
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
-  if (want > 64) want = 64;
+  if (want > 128) want = 128;
   return (int)(want < 1 ? 1 : want);
 }
 
