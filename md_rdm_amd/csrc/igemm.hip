@@ -62,6 +62,23 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Global operands are read through buffer descriptors (SRD): 32-bit byte offsets instead of 64-bit
+// pointer arithmetic, and the hardware range check returns 0 for an out-of-range offset - so zero
+// padding, ragged tile edges and the K tail cost one v_cndmask (offset := ~0u) instead of a
+// divergent branch per load.  Every operand extent is < 4 GiB (checked by the launchers).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
@@ -88,33 +105,45 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
     s_end = min(nslab_total, s_begin + per);
     if (s_begin >= s_end) return;
   }
+  const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A, p.a_bytes), srdW = make_srd(p.Wt, p.w_bytes);
 
-  // ---- per-thread A row bookkeeping (fixed for the whole K loop) ----
-  long a_off[AL];            // !TAPS: element offset of the row; TAPS: batch base pixel index
-  int a_iy[AL], a_ix[AL];    // TAPS: top-left input coordinate of the row's receptive field
+  // ---- per-thread operand bookkeeping, fixed for the whole K loop ----
+  const int kq_a = tid & 3;                    // every A load of this thread covers the same k-quad
+  unsigned a_voff[AL];                         // byte offset of (row's origin pixel, k-quad) - modulo 2^32
+  int a_iy[AL], a_ix[AL];                      // TAPS: input coordinate of tap (0,0)
   bool a_ok[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int idx = tid + i * 256;
     const int m = m0 + (idx >> 2);
     a_ok[i] = (idx < BM * 4) && (m < p.M);
-    a_off[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
-    if (a_ok[i]) {
-      if (TAPS) {
-        const int hw = G.Ho * G.Wo;
-        const int b = m / hw, rem = m - b * hw;
-        const int oy = rem / G.Wo, ox = rem - oy * G.Wo;
-        a_off[i] = (long)b * G.H * G.W;
-        a_iy[i] = G.dir > 0 ? oy * G.SH - G.PH : oy + G.PH;
-        a_ix[i] = G.dir > 0 ? ox * G.SW - G.PW : ox + G.PW;
-      } else {
-        a_off[i] = (long)m * p.lda;
-      }
+    a_iy[i] = 0; a_ix[i] = 0;
+    int pix = m;
+    if (TAPS && a_ok[i]) {
+      const int hw = G.Ho * G.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / G.Wo, ox = rem - oy * G.Wo;
+      a_iy[i] = G.dir > 0 ? oy * G.SH - G.PH : oy + G.PH;
+      a_ix[i] = G.dir > 0 ? ox * G.SW - G.PW : ox + G.PW;
+      pix = (b * G.H + a_iy[i]) * G.W + a_ix[i];          // may be "negative": offsets are modular
+    }
+    a_voff[i] = (unsigned)pix * (unsigned)(p.lda * 4) + (unsigned)(kq_a * 16);
+  }
+  unsigned b_voff[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int idx = tid + i * 256;
+    if (!B_KSTRIDED) {
+      const int row = idx >> 2, kq = idx & 3;
+      b_voff[i] = (idx < BN * 4 && n0 + row < p.N) ? (unsigned)(n0 + row) * (unsigned)(p.ldw * 4) + (unsigned)(kq * 16) : OOB;
+    } else {
+      const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
+      b_voff[i] = (idx < BK * (BN / 4) && n0 + r4 * 4 < p.N) ? (unsigned)k * (unsigned)(p.ldw * 4) + (unsigned)((n0 + r4 * 4) * 4) : OOB;
     }
   }
   const bool bnrelu = p.a_scale != nullptr;
 
-  // slab cursor: channel slab `cs` outer, filter tap (r,q) inner - advanced incrementally
+  // slab cursor: channel slab `cs` outer, filter tap (r,q) inner - advanced incrementally (scalar)
   int cur_cs = s_begin, cur_tap = 0, cur_r = 0, cur_q = 0;
   if (TAPS) { cur_cs = s_begin / ntaps; cur_tap = s_begin - cur_cs * ntaps; cur_r = cur_tap / G.KW; cur_q = cur_tap - cur_r * G.KW; }
   auto advance = [&]() {
@@ -131,37 +160,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
   // MFMA phase of the current slab; BN-ReLU / zero padding are applied when staging into LDS.
   float4 ra[AL], rb[BL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
   bool rok[AL];
-  const int kq_a = tid & 3;                                  // every A load of this thread has the same k-quad
   auto load_slab = [&]() {
     const int c0 = cur_cs * BK;
+    // wave-uniform part of the offsets
+    const unsigned a_uni = (unsigned)(c0 * 4) + (TAPS ? (unsigned)(G.dir * (cur_r * G.W + cur_q)) * (unsigned)(p.lda * 4) : 0u);
+    const unsigned b_uni = B_KSTRIDED ? (unsigned)cur_tap * (unsigned)(p.wtap * 4) + (unsigned)c0 * (unsigned)(p.ldw * 4)
+                                      : (unsigned)cur_tap * (unsigned)(p.wtap * 4) + (unsigned)(c0 * 4);
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       bool ok = a_ok[i];
-      const float* src;
       if (TAPS) {
         const int iy = a_iy[i] + G.dir * cur_r, ix = a_ix[i] + G.dir * cur_q;
-        ok = ok && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
-        src = p.A + (a_off[i] + (long)iy * G.W + ix) * p.lda + c0 + kq_a * 4;
-      } else {
-        src = p.A + a_off[i] + c0 + kq_a * 4;
+        ok = ok && (unsigned)iy < (unsigned)G.H && (unsigned)ix < (unsigned)G.W;
       }
       rok[i] = ok;
-      ra[i] = ok ? ld4(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = bld4(srdA, ok ? a_voff[i] + a_uni : OOB);
     }
     if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
 #pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const int idx = tid + i * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!B_KSTRIDED) {
-        const int row = idx >> 2, kq = idx & 3;
-        if (idx < BN * 4 && n0 + row < p.N) v = ld4(p.Wt + (long)cur_tap * p.wtap + (long)(n0 + row) * p.ldw + c0 + kq * 4);
-      } else {
-        const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
-        if (idx < BK * (BN / 4) && n0 + r4 * 4 < p.N) v = ld4(p.Wt + (long)cur_tap * p.wtap + (long)(c0 + k) * p.ldw + n0 + r4 * 4);
-      }
-      rb[i] = v;
-    }
+    for (int i = 0; i < BL; ++i) rb[i] = bld4(srdW, b_voff[i] == OOB ? OOB : b_voff[i] + b_uni);
   };
   auto store_slab = [&](int buf) {
 #pragma unroll
@@ -271,36 +288,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const int wrow = (wave / WN) * MT * 16, wcol = (wave % WN) * NT * 16;
-  const int c0 = blockIdx.x * BN, n0 = blockIdx.y * BM;
   const ConvGeom& G = p.g;
-  const int tap = TAPS ? (int)blockIdx.z / p.split_k : 0;
-  const int split = TAPS ? (int)blockIdx.z - tap * p.split_k : (int)blockIdx.z;
+  // 1-D grid.  Work item = (column tile, row tile, K split); the KH*KW taps of one work item read the
+  // SAME activation tile, so they are placed 8 block-ids apart: same XCD (blocks are dealt
+  // round-robin over the 8 XCDs), adjacent in time -> the tile is fetched from HBM once and the
+  // other taps hit that XCD's L2.  Placement only affects speed, never results.
+  const int ntaps_g = TAPS ? G.KH * G.KW : 1;
+  int tap = 0;
+  long item = blockIdx.x;
+  if (TAPS) {
+    const long L = blockIdx.x, lane8 = L & 7, seq = L >> 3;
+    tap = (int)(seq % ntaps_g);
+    item = lane8 + 8 * (seq / ntaps_g);
+    if (item >= p.n_items) return;
+  }
+  const int ctiles = (p.C + BN - 1) / BN, ntiles = (p.N + BM - 1) / BM;
+  const int ct = (int)(item % ctiles);
+  const long t2 = item / ctiles;
+  const int nt = (int)(t2 % ntiles), split = (int)(t2 / ntiles);
+  const int c0 = ct * BN, n0 = nt * BM;
   const int tr = TAPS ? tap / G.KW : 0, tq = TAPS ? tap - tr * G.KW : 0;
   const int Mpix = G.B * G.Ho * G.Wo;
   const int nslab_total = (Mpix + BK - 1) / BK;
   const int per = (nslab_total + p.split_k - 1) / p.split_k;
   const int s_begin = split * per, s_end = min(nslab_total, s_begin + per);
   if (s_begin >= s_end) return;
+  const __amdgpu_buffer_rsrc_t srdG = make_srd(p.G, p.g_bytes), srdX = make_srd(p.Xs, p.x_bytes);
 
-  // B rows (channels) are fixed per thread: hoist the BN affine
+  // fixed per thread: k (pixel within the slab) and the float4 column group of each load
+  unsigned a_voff[AL];  int a_m[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int idx = tid + i * 256;
+    const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
+    const bool ok = idx < BK * (BM / 4) && n0 + r4 * 4 < p.N;
+    a_m[i] = ok ? s_begin * BK + k : 0x40000000;             // "never < Mpix" for dead lanes
+    a_voff[i] = (unsigned)(s_begin * BK + k) * (unsigned)(p.ldg * 4) + (unsigned)((n0 + r4 * 4) * 4);
+  }
   float4 bsc[BL], bsh[BL];
+  unsigned b_col[BL]; int b_m[BL];
+  int pb_[BL], poy[BL], pox[BL];
   const bool bnrelu = p.x_scale != nullptr;
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
     const int idx = tid + i * 256;
-    const int r4 = idx % (BN / 4);
-    bsc[i] = make_float4(1.f, 1.f, 1.f, 1.f); bsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bnrelu && idx < BK * (BN / 4) && c0 + r4 * 4 < p.C) { bsc[i] = ld4(p.x_scale + c0 + r4 * 4); bsh[i] = ld4(p.x_shift + c0 + r4 * 4); }
-  }
-
-  // per-thread pixel cursors of the B loads (k index is fixed per thread; the pixel advances by BK
-  // every slab) - incremental (b, oy, ox) instead of two integer divisions per load per slab
-  int pb_[BL], poy[BL], pox[BL];
-#pragma unroll
-  for (int i = 0; i < BL; ++i) {
-    const int idx = tid + i * 256;
-    const int k = idx / (BN / 4);
+    const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
+    const bool ok = idx < BK * (BN / 4) && c0 + r4 * 4 < p.C;
     const int m = s_begin * BK + k;
+    b_m[i] = ok ? m : 0x40000000;
+    b_col[i] = (unsigned)((c0 + r4 * 4) * 4);
+    bsc[i] = make_float4(1.f, 1.f, 1.f, 1.f); bsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bnrelu && ok) { bsc[i] = ld4(p.x_scale + c0 + r4 * 4); bsh[i] = ld4(p.x_shift + c0 + r4 * 4); }
     pb_[i] = 0; poy[i] = 0; pox[i] = m;
     if (TAPS) {
       const int hw = G.Ho * G.Wo;
@@ -309,36 +347,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       poy[i] = rem / G.Wo; pox[i] = rem - poy[i] * G.Wo;
     }
   }
+
   float4 ra[AL], rb[BL];
   bool rok[BL];
-  auto load_slab = [&](int s) {
+  auto load_slab = [&]() {
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const int idx = tid + i * 256;
-      const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
-      const int m = s * BK + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < BK * (BM / 4) && m < Mpix && n0 + r4 * 4 < p.N) v = ld4(p.G + (long)m * p.ldg + n0 + r4 * 4);
-      ra[i] = v;
+      ra[i] = bld4(srdG, a_m[i] < Mpix ? a_voff[i] : OOB);
+      a_m[i] += BK; a_voff[i] += (unsigned)(BK * p.ldg * 4);
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-      const int idx = tid + i * 256;
-      const int k = idx / (BN / 4), r4 = idx - k * (BN / 4);
-      const int m = s * BK + k;
-      bool ok = idx < BK * (BN / 4) && m < Mpix && c0 + r4 * 4 < p.C;
-      long pix = m;
+      bool ok = b_m[i] < Mpix;
+      int pix = b_m[i];
       if (TAPS) {
         const int iy = poy[i] * G.SH - G.PH + tr, ix = pox[i] * G.SW - G.PW + tq;
-        ok = ok && iy >= 0 && iy < G.H && ix >= 0 && ix < G.W;
-        pix = ((long)pb_[i] * G.H + iy) * G.W + ix;
-        // advance this thread's pixel cursor by one slab (BK output pixels)
-        pox[i] += BK;
+        ok = ok && (unsigned)iy < (unsigned)G.H && (unsigned)ix < (unsigned)G.W;
+        pix = (pb_[i] * G.H + iy) * G.W + ix;
+        pox[i] += BK;                                        // advance the pixel cursor by one slab
         while (pox[i] >= G.Wo) { pox[i] -= G.Wo; ++poy[i]; }
         while (poy[i] >= G.Ho) { poy[i] -= G.Ho; ++pb_[i]; }
       }
       rok[i] = ok;
-      rb[i] = ok ? ld4(p.Xs + pix * p.ldx + c0 + r4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = bld4(srdX, ok ? (unsigned)pix * (unsigned)(p.ldx * 4) + b_col[i] : OOB);
+      b_m[i] += BK;
     }
   };
   auto store_slab = [&](int buf) {
@@ -368,13 +400,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_slab(s_begin);
+  load_slab();
   store_slab(0);
   __syncthreads();
   int buf = 0;
   for (int s = s_begin; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
-    if (more) load_slab(s + 1);
+    if (more) load_slab();
     mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
     if (more) store_slab(buf ^ 1);
     __syncthreads();
@@ -489,6 +521,13 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
   }
   a.split_k = split;
+  {
+    const long npix = (long)a.g.B * a.g.H * a.g.W, nt = taps ? a.g.KH * a.g.KW : 1;
+    const long ab = ((npix - 1) * a.lda + a.C) * 4;
+    const long wb = b_kstrided ? ((nt - 1) * a.wtap + (long)(a.C - 1) * a.ldw + a.N) * 4 : ((nt - 1) * a.wtap + (long)(a.N - 1) * a.ldw + a.C) * 4;
+    if (ab >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("conv: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+    a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
+  }
   ProfScope prof(s, 2.0 * a.M * a.N * (double)kslabs * 16);
 
 #define RDM_FWD_DISPATCH(TAPS_, BKS_)                                                           \
@@ -509,9 +548,12 @@ template <int MT, int NT, int WM, int WN>
 static void launch_wgrad_cfg(const WgradArgs& a, bool taps, hipStream_t s) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   const int ntaps = taps ? a.g.KH * a.g.KW : 1;
-  dim3 grid(cdiv(a.C, BN), cdiv(a.N, BM), ntaps * a.split_k);
-  if (taps) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, a);
+  WgradArgs b = a;
+  b.n_items = (long)cdiv(a.C, BN) * cdiv(a.N, BM) * a.split_k;
+  const long padded = (b.n_items + 7) / 8 * 8;               // whole groups of 8 so every (item, tap) pair exists
+  dim3 grid((unsigned)(taps ? padded * ntaps : b.n_items));
+  if (taps) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, b);
 }
 
 int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
@@ -527,6 +569,11 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
   if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs);
+  {
+    const long gb = ((Mpix - 1) * a.ldg + a.N) * 4, xb = (((long)a.g.B * a.g.H * a.g.W - 1) * a.ldx + a.C) * 4;
+    if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+    a.g_bytes = (unsigned)gb; a.x_bytes = (unsigned)xb;
+  }
   ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
   if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
   else launch_wgrad_cfg<4, 3, 2, 2>(a, taps, s);          // 128 x 96

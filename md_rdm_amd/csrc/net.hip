@@ -92,7 +92,7 @@ struct Bump {
   template <typename T> size_t take(size_t n) { off = (off + 255) & ~(size_t)255; size_t o = off; off += n * sizeof(T); return o; }
 };
 
-struct LayerWs { size_t Y, statY, bn1, bn2, w2p; };      // bn*: [scale|shift|mean|rstd] x C floats
+struct LayerWs { size_t Y, statY, bn1, bn2, w2p, bs2, bs1; };   // bs*: backward [sum dz | sum dz*x] f64 slots      // bn*: [scale|shift|mean|rstd] x C floats
 struct BlockGeom { int H, W, M, ctot, cb; };
 
 }  // namespace
@@ -106,7 +106,7 @@ struct NetImpl {
   std::vector<LayerWs> lws[4];
   size_t transP[3], transBn[3];
   // backward scratch
-  size_t G[4], dZ, dZ1, s0, s1, cA, cB, cC, dP, dW3, gE1, dWstem, dL, tmp64;
+  size_t G[4], dZ, dZ1, cA, cB, cC, dP, dW3, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
   size_t total;
   int training_saved = 1;
 
@@ -160,7 +160,15 @@ struct NetImpl {
     for (int t = 0; t < 3; ++t) maxP = std::max(maxP, (size_t)bg[t + 1].M * kTrans[t].cin);
     dZ = a.take<float>(maxMC);
     dZ1 = a.take<float>(maxMCin);
-    s0 = a.take<double>(maxC); s1 = a.take<double>(maxC);
+    // backward reductions: one slot per BatchNorm, zeroed by ONE memset at the start of backward
+    bwd_stats_begin = a.take<double>(0);
+    for (int b = 0; b < 4; ++b)
+      for (int i = 0; i < kBlocks[b].layers; ++i) {
+        lws[b][i].bs2 = a.take<double>(2 * (size_t)bg[b].cb);
+        lws[b][i].bs1 = a.take<double>(2 * (size_t)(kBlocks[b].cin + i * GROWTH));
+      }
+    for (int t = 0; t < 3; ++t) transBs[t] = a.take<double>(2 * (size_t)kTrans[t].cin);
+    bwd_stats_end = a.take<double>(0);
     cA = a.take<float>(maxC); cB = a.take<float>(maxC); cC = a.take<float>(maxC);
     dP = a.take<float>(maxP);
     dW3 = a.take<float>(9 * (size_t)GROWTH * maxCb);
@@ -268,8 +276,6 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
   float* G = at<float>(ws, n.G[b]);
   float* dZ = at<float>(ws, n.dZ);
   float* dZ1 = at<float>(ws, n.dZ1);
-  double* s0 = at<double>(ws, n.s0);
-  double* s1 = at<double>(ws, n.s1);
   float* cA = at<float>(ws, n.cA); float* cB = at<float>(ws, n.cB); float* cC = at<float>(ws, n.cC);
   float* dW3 = at<float>(ws, n.dW3);
   int rc;
@@ -294,8 +300,8 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
       if ((rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, s))) return rc;
     }
     // ---- conv2 dgrad -> dZ, gated by relu2, with the norm2 backward reductions ----
-    RDM_HIP_OK(hipMemsetAsync(s0, 0, cb * sizeof(double), s));
-    RDM_HIP_OK(hipMemsetAsync(s1, 0, cb * sizeof(double), s));
+    double* s0 = at<double>(ws, W.bs2);
+    double* s1 = s0 + cb;
     FwdArgs d{};
     d.g = geom3x3(n.B, g.H, g.W, -1);
     d.A = go; d.lda = g.ctot; d.C = GROWTH;
@@ -320,8 +326,8 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
       if ((rc = launch_conv_wgrad(w, s))) return rc;
     }
     // ---- conv1 dgrad -> dZ1, gated by relu1, with the norm1 backward reductions ----
-    RDM_HIP_OK(hipMemsetAsync(s0, 0, cin * sizeof(double), s));
-    RDM_HIP_OK(hipMemsetAsync(s1, 0, cin * sizeof(double), s));
+    s0 = at<double>(ws, W.bs1);
+    s1 = s0 + cin;
     FwdArgs e{};
     e.g = geom1x1(n.B, g.H, g.W);
     e.A = dZ; e.lda = cb; e.C = cb;
@@ -350,8 +356,8 @@ int backward_transition(NetImpl& n, int t, void* ws, void* const* T, void* const
   float* P = at<float>(ws, n.transP[t]);
   float* bn = at<float>(ws, n.transBn[t]);
   float* dP = at<float>(ws, n.dP);
-  double* s0 = at<double>(ws, n.s0);
-  double* s1 = at<double>(ws, n.s1);
+  double* s0 = at<double>(ws, n.transBs[t]);
+  double* s1 = s0 + C;
   float* cA = at<float>(ws, n.cA); float* cB = at<float>(ws, n.cB); float* cC = at<float>(ws, n.cC);
   const BnIdx& b = reg().trans_bn[t];
   const int wi = reg().trans_conv[t];
@@ -371,8 +377,6 @@ int backward_transition(NetImpl& n, int t, void* ws, void* const* T, void* const
   d.Wt = F(T, wi); d.wtap = 0; d.ldw = C;
   d.out = dP; d.ldc = C; d.M = gn.M; d.N = C;
   if ((rc = launch_conv_fwd(d, true, EPI_STORE, s)) < 0) return rc;
-  RDM_HIP_OK(hipMemsetAsync(s0, 0, C * sizeof(double), s));
-  RDM_HIP_OK(hipMemsetAsync(s1, 0, C * sizeof(double), s));
   if ((rc = launch_trans_pool_bwd_reduce(dP, blk, g.ctot, bn, bn + C, n.B, g.H, g.W, C, s0, s1, s))) return rc;
   const double count = (double)n.B * (g.H + 1) * (g.W + 1);
   if ((rc = launch_bn_bwd_coeffs(s0, s1, count, F(T, b.w), bn + 2 * C, bn + 3 * C, cA, cB, cC, Gr[b.w] ? F(Gr, b.w) : nullptr,
@@ -519,6 +523,7 @@ int rdm_net_backward(rdm_net* net, const float* dlogits, void* const* T, void* c
   int rc;
   for (int seg = first_seg; seg <= last_seg; ++seg) {
     if (seg == 0) {
+      RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.bwd_stats_begin), 0, n.bwd_stats_end - n.bwd_stats_begin, s));
       const BlockGeom& g = n.bg[3];
       float* dL = at<float>(ws, n.dL);
       if ((rc = launch_nchw_to_nhwc(dlogits, dL, 192, n.B, 180, g.H * g.W, s))) return rc;
