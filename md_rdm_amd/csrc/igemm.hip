@@ -83,7 +83,7 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int AL = (BM * 4 + 255) / 256;                         // float4 loads of A per thread per slab
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
       bool ok = a_ok[i];
       if (TAPS) {
         const int iy = a_iy[i] + G.dir * cur_r, ix = a_ix[i] + G.dir * cur_q;
-        ok = ok && (unsigned)iy < (unsigned)G.H && (unsigned)ix < (unsigned)G.W;
+        ok = ok & ((unsigned)iy < (unsigned)G.H) & ((unsigned)ix < (unsigned)G.W);
       }
       rok[i] = ok;
       ra[i] = bld4(srdA, ok ? a_voff[i] + a_uni : OOB);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs p) {
 // (K = output pixels).  dW[tap][n][c] += sum_m G[m][n] * f(X[pix(m,tap)][c]).
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, int WM, int WN, bool TAPS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int AL = (BK * (BM / 4) + 255) / 256, BL = (BK * (BN / 4) + 255) / 256;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       int pix = b_m[i];
       if (TAPS) {
         const int iy = poy[i] * G.SH - G.PH + tr, ix = pox[i] * G.SW - G.PW + tq;
-        ok = ok && (unsigned)iy < (unsigned)G.H && (unsigned)ix < (unsigned)G.W;
+        ok = ok & ((unsigned)iy < (unsigned)G.H) & ((unsigned)ix < (unsigned)G.W);
         pix = (pb_[i] * G.H + iy) * G.W + ix;
         pox[i] += BK;                                        // advance the pixel cursor by one slab
         while (pox[i] >= G.Wo) { pox[i] -= G.Wo; ++poy[i]; }
