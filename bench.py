@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--width", type=int, default=304)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path); gloo only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -43,8 +44,13 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+            local_rank = local_rank % max(ndev, 1)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the HBM-bound kernels of the path: achieved GB/s of the
+compulsory bytes against the MI355X HBM3E peak (8 TB/s spec; ~6.3 TB/s attainable).  One JSON line
+per kernel.  bench.py remains the driver-facing headline benchmark."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from md_rdm_amd import _lib, filler  # noqa: E402
+from md_rdm_amd.network import RDM_Net, computations as cp  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def report(name, seconds, nbytes, note):
+    gbs = nbytes / seconds / 1e9
+    print(json.dumps({"kernel": name, "ms": round(seconds * 1e3, 4), "algorithmic_MB": round(nbytes / 1e6, 2), "achieved_GBps": round(gbs, 1),
+                      "hbm_peak_GBps": PEAK, "frac": round(gbs / PEAK, 4), "note": note}), flush=True)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B = 16
+    quant = RDM_Net.Quantization()
+    # d_10 scale: 128x128 relative map, 64 pages of 16x16
+    dn = torch.from_numpy(filler.log_uniform("bo.dn", (B, 1, 128, 128), 0.5, 2.0)).to(dev)
+    dn1 = cp.resize(dn, 64)
+    q, inv = quant.device_tables(7, dev)
+    R = cp.ratio_grid_lloyd_paged(dn, dn1, q, inv)
+    t = timeit(lambda: cp.ratio_grid_lloyd_paged(dn, dn1, q, inv))
+    report("ratio_grid_lloyd_paged d_10 B=16", t, R.numel() * 8 + dn.numel() * 4 + dn1.numel() * 8, "compulsory: write 1024x256x64 f64 grid (+ read maps)")
+    Rf = R.float()
+    t = timeit(lambda: cp.als_pages(Rf, limit=100), reps=10)
+    comp = Rf.numel() * 4 + 1024 * 256 * 4
+    report("als_rank1 d_10 B=16 (1024 matrices, 100 iters) - compulsory bytes", t, comp, "R read once (LDS-resident), p written; + iterate history 1024x101x256x4 B")
+    report("als_rank1 d_10 B=16 - streaming model of the reference algorithm", t, 301 * 65536 * 1024, "3 passes over R per iteration + 1 (SURVEY 8(d)): the reference's own traffic, never issued here")
+    t = timeit(lambda: cp.als_pages(R, limit=100), reps=10)
+    report("als_rank1 d_10 B=16, float64 grid input", t, R.numel() * 8 + 1024 * 256 * 4, "as Ordinal_Layer.forward feeds it (f64 grid -> f32 in LDS)")
+    # decomposition / recombination at the harness sizes
+    y = torch.from_numpy(filler.log_uniform("bo.y", (B, 1, 128, 128), 0.5, 9.5)).double().to(dev)
+    t = timeit(lambda: cp.decompose_depth_map([], y, 7))
+    report("decompose_depth_map n=7 B=16", t, y.numel() * 8 * (1 + 4 / 3), "read map, write packed pyramid")
+    # fused AdamW over the flat parameter buffer
+    n = 90_529_720
+    p, g, m, v = (torch.zeros(n, device=dev) for _ in range(4))
+    L = _lib.lib()
+    t = timeit(lambda: _lib.check(L.rdm_adamw_fused(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, _lib.stream())))
+    report("adamw_fused 90.5M params", t, n * 28, "28 B/param: read p,g,m,v, write p,m,v")
+    lg = torch.from_numpy(filler.uniform("bo.lg", (B, 180, 8, 10), -2, 3)).to(dev)
+    t = timeit(lambda: cp.dorn_ordinal_regression(lg))
+    report("dorn_fwd B=16 8x10", t, lg.numel() * 4 + lg.numel() // 2 * 8 + B * 80 * 8, "latency-bound (1.5 MB)")
+
+
+if __name__ == "__main__":
+    main()

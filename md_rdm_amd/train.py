@@ -1,0 +1,118 @@
+"""Counterpart of the reference's ``train.py`` (flags :9-26) on the native stack.  Lightning is not
+used: the step logic is md_rdm_amd/harness.py (restating network/module.py).  Datasets are out of
+scope of the hot path; ``--synthetic`` feeds hash-generated NYU-shaped batches.
+
+  python -m md_rdm_amd.train --synthetic --batch_size 16 --max_steps 20
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m md_rdm_amd.train --synthetic --gpus 8
+"""
+import os
+import random
+import sys
+import time
+from argparse import ArgumentParser
+
+import torch
+
+
+class ReduceLROnPlateau:
+    """module.py:42-46: ReduceLROnPlateau(optimizer, 'max', patience=2) monitoring val_delta1
+    (torch defaults: factor 0.1, threshold 1e-4 rel, cooldown 0, min_lr 0)."""
+
+    def __init__(self, optimizer, mode="max", patience=2, factor=0.1, threshold=1e-4):
+        self.opt, self.mode, self.patience, self.factor, self.threshold = optimizer, mode, patience, factor, threshold
+        self.best, self.bad = None, 0
+
+    def step(self, metric):
+        better = self.best is None or (metric > self.best * (1 + self.threshold) if self.mode == "max" else metric < self.best * (1 - self.threshold))
+        if better:
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+            if self.bad > self.patience:
+                self.opt.lr *= self.factor
+                for g in self.opt.small.param_groups:
+                    g["lr"] = self.opt.lr
+                self.bad = 0
+
+
+def delta1(pred_log, target):
+    """metrics.py delta1 on the recombined log-depth map vs the normalised target."""
+    p = torch.exp(pred_log)
+    r = torch.maximum(p / target, target / p)
+    return (r < 1.25).double().mean().item()
+
+
+def main(argv=None):
+    parser = ArgumentParser("Trains mono depth estimation models (MI355X-native stack)")
+    parser.add_argument("--seed", default=None, type=int)
+    parser.add_argument("--precision", default=32, type=int, help="32 only: the exact-f32 MFMA path (the reference's AMP 16 is a later round)")
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--dev", action="store_true", help="one train + one val step (Lightning fast_dev_run)")
+    parser.add_argument("--overfit", action="store_true", help="reuse one batch")
+    parser.add_argument("--min_epochs", default=1, type=int)
+    parser.add_argument("--max_epochs", default=1, type=int)
+    parser.add_argument("--max_steps", default=8, type=int, help="steps per epoch in --synthetic mode")
+    parser.add_argument("--metrics", default=["delta1"], nargs="+")
+    parser.add_argument("--worker", default=6, type=int)
+    parser.add_argument("--find_learning_rate", action="store_true")
+    parser.add_argument("--detect_anomaly", action="store_true")
+    parser.add_argument("--learning_rate", type=float, default=1e-4)
+    parser.add_argument("--batch_size", type=int, default=4)
+    parser.add_argument("--nyu_path", type=str, default=None)
+    parser.add_argument("--synthetic", action="store_true")
+    parser.add_argument("--size", type=int, nargs=2, default=[226, 226], help="input HxW (module.py:19 feeds 226x226)")
+    args = parser.parse_args(argv)
+    if args.precision != 32:
+        raise SystemExit("only --precision 32 is built")
+    if not args.synthetic:
+        raise SystemExit("dataset loaders are out of scope of this round (SURVEY.md 8(f)); use --synthetic")
+    if args.seed is None:
+        args.seed = random.randrange(4294967295)
+    torch.manual_seed(args.seed)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from . import filler, harness, parallel
+    from .network.RDM_Net import DepthEstimationNet
+    model = DepthEstimationNet().to(dev)
+    model.flatten_parameters()
+    sync = parallel.attach(model)
+    opt = harness.FusedAdamW(model, lr=args.learning_rate)
+    sched = ReduceLROnPlateau(opt, "max", patience=2)
+    H, W = args.size
+    steps = 1 if args.dev else args.max_steps
+    for epoch in range(args.max_epochs):
+        model.train()
+        t0 = time.time()
+        for it in range(steps):
+            seed = 1234 + rank if args.overfit else 1234 + rank + 1000 * (epoch * steps + it)
+            x, y = filler.synthetic_batch(args.batch_size, H, W, seed=seed)
+            opt.zero_grad()
+            loss, parts = harness.training_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+            loss.backward()
+            opt.step(grad_scale=sync.finish())
+            if rank == 0:
+                print(f"epoch {epoch} step {it} loss {loss.item():.4f} MSE {parts['mse'].item():.4f} Ord_Loss {parts['ord_loss'].item():.4f} "
+                      f"Fine_Detail {parts['fine_detail_loss'].item():.4f}", flush=True)
+        torch.cuda.synchronize()
+        model.eval()
+        with torch.no_grad():
+            x, y = filler.synthetic_batch(1, H, W, seed=99)
+            y_hat, y_n = harness.validation_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+        d1 = delta1(y_hat, y_n)
+        sched.step(d1)
+        if rank == 0:
+            print(f"epoch {epoch}: {steps * args.batch_size * world / (time.time() - t0):.1f} img/s, val_delta1 {d1:.4f}, lr {opt.lr:g}", flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
