@@ -1,0 +1,174 @@
+"""WSM decoder block (reference ``network/RDM_Net.py:163-236``, factories ``:493-515``) on the fp32
+MFMA conv family.  Dormant in the reference graph (decoders d_2..d_5, d_7..d_10 are commented out,
+SURVEY.md F3) but in scope as an operator; same parameter names / shapes / init as the reference
+module, forward AND backward through the C ABI (rdm_conv2d_fwd / _dgrad / _wgrad).
+
+How each reference op maps onto the one implicit-GEMM family (NHWC, channels padded to 16):
+  * 1x1 / 3x3 / 5x5 convs            -> direct;
+  * ConvTranspose2d(k=2, s=2)        -> 1x1 conv to 4*C channels (one group per output phase) followed
+                                        by a pixel shuffle (pure re-indexing);
+  * strip conv (3,k) stride (1,k) after ZeroPad2d((0,0,1,1)) -> a (3,1) conv, pad (1,0), over the
+    tensor viewed as (B, H, 1, W*C): an NHWC row IS the contiguous "pixel" of W*C channels;
+  * strip conv (k,3) stride (k,1) after ZeroPad2d((1,1,0,0)) -> the same on the spatially transposed
+    tensor;  ``repeat`` of the compressed row/column is an expand + copy into the output slice.
+Layout shuffles (NCHW<->NHWC, pixel shuffle, expand, channel concat) are device-side view/copy ops.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import ConvDesc
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+class _ConvNHWC(torch.autograd.Function):
+    """y = conv(x, w) + b on NHWC tensors whose channel counts are already multiples of 16.
+    x (B,H,W,Cin), w PyTorch layout (Cout,Cin,kh,kw) [zero-padded], returns (B,Ho,Wo,Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kh, kw, ph, pw):
+        L = _lib.lib()
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        x = x.contiguous()
+        wp = torch.empty(kh * kw, Cout, Cin, device=x.device, dtype=torch.float32)
+        _lib.check(L.rdm_pack_conv_weight(_lib.ptr(w.contiguous()), _lib.ptr(wp), Cout, Cin, kh, kw, Cout, _lib.stream()))
+        Ho, Wo = H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+        y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+        d = ConvDesc(B, H, W, Cin, Cin, Cout, Cout, kh, kw, 1, 1, ph, pw)
+        _lib.check(L.rdm_conv2d_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(b) if b is not None else None, None, None, _lib.ptr(y), None, None, _lib.stream()))
+        ctx.save_for_backward(x, wp)
+        ctx.geom = (B, H, W, Cin, Cout, kh, kw, ph, pw, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, wp = ctx.saved_tensors
+        B, H, W, Cin, Cout, kh, kw, ph, pw, has_b = ctx.geom
+        gy = gy.contiguous()
+        d = ConvDesc(B, H, W, Cin, Cin, Cout, Cout, kh, kw, 1, 1, ph, pw)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.rdm_conv2d_dgrad(C.byref(d), _lib.ptr(gy), _lib.ptr(wp), _lib.ptr(gx), Cin, None, 0, None, None, None, None, _lib.stream()))
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros_like(wp)
+            _lib.check(L.rdm_conv2d_wgrad(C.byref(d), _lib.ptr(gy), _lib.ptr(x), None, None, _lib.ptr(dwp), _lib.stream()))
+            gw = torch.empty(Cout, Cin, kh, kw, device=x.device, dtype=torch.float32)
+            _lib.check(L.rdm_unpack_conv_weight(_lib.ptr(dwp), _lib.ptr(gw), Cout, Cin, kh, kw, Cout, _lib.stream()))
+        if has_b and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 1, 2))
+        return gx, gw, gb, None, None, None, None
+
+
+def _padded(w, b, cin_p, cout_p):
+    """zero-pad a (Cout,Cin,kh,kw) weight / (Cout,) bias to the 16-multiples the kernels contract over"""
+    Cout, Cin = w.shape[0], w.shape[1]
+    if Cin != cin_p or Cout != cout_p:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_p - Cin, 0, cout_p - Cout))
+        if b is not None:
+            b = torch.nn.functional.pad(b, (0, cout_p - Cout))
+    return w, b
+
+
+def conv_nhwc(x, conv: nn.Conv2d, cin=None):
+    """Apply an nn.Conv2d's parameters (stride 1) to an NHWC tensor whose channel dim may be zero-padded."""
+    kh, kw = conv.kernel_size
+    ph, pw = conv.padding
+    cin_p = x.shape[3]
+    cout_p = _pad16(conv.out_channels)
+    w, b = _padded(conv.weight, conv.bias, cin_p, cout_p)
+    return _ConvNHWC.apply(x, w, b, kh, kw, ph, pw)
+
+
+def _make_wsm_vertical_(in_channels, out_channels, kernel_size, stride):
+    """RDM_Net.py:493-503 (parameter holder: ZeroPad2d((0,0,1,1)) + Conv2d)."""
+    return nn.Sequential(nn.ZeroPad2d((0, 0, 1, 1)), nn.Conv2d(in_channels, out_channels, kernel_size, stride))
+
+
+def _make_wsm_horizontal_(in_channels, out_channels, kernel_size, stride):
+    """RDM_Net.py:505-515."""
+    return nn.Sequential(nn.ZeroPad2d((1, 1, 0, 0)), nn.Conv2d(in_channels, out_channels, kernel_size, stride))
+
+
+class WSMLayer(nn.Module):
+    """Drop-in for the reference WSMLayer(in_channels, kernel_size, stride, layer_id)."""
+
+    def __init__(self, in_channels, kernel_size, stride, layer_id):
+        super().__init__()
+        self.deconv1 = nn.Sequential(nn.ConvTranspose2d(in_channels, in_channels, kernel_size=2, stride=2))
+        kernel_in = int(in_channels / 4)
+        wsm_in = int(in_channels / 8)
+        self.conv1_1 = nn.Conv2d(in_channels, kernel_in, 1)
+        self.conv1_2 = nn.Conv2d(in_channels, kernel_in, 1)
+        self.conv1_3 = nn.Conv2d(in_channels, kernel_in, 1)
+        self.conv1_4 = nn.Conv2d(in_channels, wsm_in, 1)
+        self.conv1_5 = nn.Conv2d(in_channels, wsm_in, 1)
+        self.conv2_1 = nn.Conv2d(kernel_in, kernel_in, 3, padding=1)
+        self.conv2_2 = nn.Conv2d(kernel_in, kernel_in, 5, padding=2)
+        self.wsm_wx3 = _make_wsm_vertical_(wsm_in, wsm_in, (3, kernel_size), (1, stride))
+        self.wsm_3xh = _make_wsm_horizontal_(wsm_in, wsm_in, (kernel_size, 3), (stride, 1))
+        self.id = layer_id
+        raw = 2208 if self.id == 1 else int(2 * in_channels)
+        self.input_adjustment_layer = nn.Conv2d(raw, in_channels, 1)
+        self.in_channels, self.kernel_in, self.wsm_in, self.k = in_channels, kernel_in, wsm_in, kernel_size
+
+    # ---- pieces -----------------------------------------------------------------------------
+    def _deconv(self, x):
+        """ConvTranspose2d(k=2,s=2): 1x1 conv to 4*C (phase-major) + pixel shuffle."""
+        ct = self.deconv1[0]
+        Cc = self.in_channels
+        cp = _pad16(Cc)
+        B, H, W, cin_p = x.shape
+        # weight (Cin, Cout, 2, 2) -> conv weight ((r,s,n), c, 1, 1) with each phase padded to cp
+        w = ct.weight.permute(2, 3, 1, 0)                                   # (2,2,Cout,Cin)
+        w = torch.nn.functional.pad(w, (0, cin_p - Cc, 0, cp - Cc)).reshape(4 * cp, cin_p, 1, 1)
+        b = torch.nn.functional.pad(ct.bias, (0, cp - Cc)).repeat(4)
+        y = _ConvNHWC.apply(x, w, b, 1, 1, 0, 0)                              # (B,H,W,4*cp)
+        return y.view(B, H, W, 2, 2, cp).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cp)
+
+    def _strip_rows(self, x, weight, bias):
+        """(3,k)/(1,k) conv after top/bottom zero pad on x (B,H,W=k,Cp), weight (n,c,3,k): every row
+        becomes ONE pixel of W*Cp channels, the conv a (3,1) conv with pad (1,0)."""
+        B, H, W, cpad = x.shape
+        n, c = weight.shape[0], weight.shape[1]
+        assert W == weight.shape[3] and weight.shape[2] == 3, "WSM strip convs perform exactly one convolution per row"
+        np_ = _pad16(n)
+        w = torch.nn.functional.pad(weight.permute(0, 3, 1, 2), (0, 0, 0, cpad - c))          # (n, k, cpad, 3)
+        w = w.reshape(n, W * cpad, 3, 1)
+        w, b = _padded(w, bias, W * cpad, np_)
+        return _ConvNHWC.apply(x.reshape(B, H, 1, W * cpad), w, b, 3, 1, 1, 0)               # (B,H,1,np_)
+
+    def forward(self, x):
+        """x: (B, raw, H, W) NCHW like the reference; returns (B, in_channels, 2H, 2W) NCHW."""
+        if not x.is_cuda:
+            raise _lib.RdmError("WSMLayer runs on the GPU only")
+        B, raw, H, W = x.shape
+        xh = x.permute(0, 2, 3, 1)
+        rp = _pad16(raw)
+        if rp != raw:
+            xh = torch.nn.functional.pad(xh, (0, rp - raw))
+        xh = xh.contiguous().float()
+        t = conv_nhwc(xh, self.input_adjustment_layer)                         # (B,H,W,Cp)
+        out1 = self._deconv(t)                                                 # (B,2H,2W,Cp)
+        o1 = conv_nhwc(out1, self.conv1_1)
+        o2 = conv_nhwc(conv_nhwc(out1, self.conv1_2), self.conv2_1)
+        o3 = conv_nhwc(conv_nhwc(out1, self.conv1_3), self.conv2_2)
+        o4 = conv_nhwc(out1, self.conv1_4)
+        o5 = conv_nhwc(out1, self.conv1_5)
+        S = 2 * H
+        assert S == 2 * W == self.k, "WSM strip kernels span the whole (square) map"
+        cv, ch = self.wsm_wx3[1], self.wsm_3xh[1]
+        col = self._strip_rows(o4, cv.weight, cv.bias)                          # (B,S,1,n): one value per row
+        row = self._strip_rows(o5.transpose(1, 2), ch.weight.transpose(2, 3), ch.bias)   # transposed map: one value per column
+        ki, wi = self.kernel_in, self.wsm_in
+        completion_horizontal = col[..., :wi].expand(B, S, S, wi)              # repeat along W (RDM_Net.py:221)
+        completion_vertical = row[..., :wi].transpose(1, 2).expand(B, S, S, wi)  # repeat along H (:222)
+        out = torch.cat((o1[..., :ki], o2[..., :ki], o3[..., :ki], completion_vertical, completion_horizontal), 3)
+        return out.permute(0, 3, 1, 2).contiguous()
