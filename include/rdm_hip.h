@@ -45,6 +45,8 @@ int rdm_version(void);
  * them (HOST sync - never call it inside a graph capture), returns the summed kernel time (ms),
  * the FLOPs those launches executed and their count, and clears the record. */
 void rdm_profile_enable(int32_t on);
+/* development switch between kernel variants for in-process A/B timing (0 = shipped) */
+void rdm_debug_variant(int32_t v);
 int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------

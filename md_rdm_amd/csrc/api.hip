@@ -6,6 +6,7 @@
 #include "elementwise.h"
 
 namespace rdm {
+extern int g_variant;
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -33,6 +34,7 @@ extern "C" {
 const char* rdm_last_error_string(void) { return g_err; }
 int rdm_version(void) { return 100; }
 
+void rdm_debug_variant(int32_t v) { rdm::g_variant = v; }
 void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
 int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches) {
   int n = 0;

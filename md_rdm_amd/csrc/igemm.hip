@@ -61,6 +61,56 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
       for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
 }
 
+// K-contiguous operands (NHWC activations, forward weights) are staged as a [row][16] image with an
+// XOR swizzle of the four 16-byte k-chunks: chunk' = chunk ^ ((-(row >> 2)) & 3).  With it every
+// ds_read_b128 lane group of a fragment read (lane -> row l&15, chunk l>>4) and every ds_write_b128
+// of the staging pass touches 16 distinct 4-bank slots: conflict-free with NO padding (16 KB per
+// 256-row buffer) and 4x fewer LDS instructions than a transposing [k][row] image.
+// Lane group g then owns k = 4g..4g+3 of the slab; MFMA step j contracts k = 4g + j on BOTH operands
+// (the contraction order inside a slab is free as long as A and B agree).
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+
+template <int MT, int NT, bool B_KSTRIDED>
+__device__ __forceinline__ void mma_slab_sw(const float* __restrict__ As, const float* __restrict__ Bs, int ldb, int wrow, int wcol,
+                                            int l16, int g, f32x4 (&acc)[MT][NT]) {
+  float4 a[MT];
+  const int ch = (g ^ swz(l16)) * 4;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wrow + i * 16 + l16) * BK + ch]);
+  // k-step outer, accumulator tiles inner: consecutive MFMAs hit different accumulators (a dependent
+  // v_mfma_f32_16x16x4_f32 would wait 40 cycles instead of issuing every 32)
+  if (!B_KSTRIDED) {
+    float4 b[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wcol + j * 16 + l16) * BK + ch]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float av = q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w;
+          const float bv = q == 0 ? b[j].x : q == 1 ? b[j].y : q == 2 ? b[j].z : b[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+        }
+  } else {
+    float b[4][NT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[q][j] = Bs[(4 * g + q) * ldb + wcol + j * 16 + l16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float av = q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][j], acc[i][j], 0, 0, 0);
+        }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Global operands are read through buffer descriptors (SRD): 32-bit byte offsets instead of 64-bit
 // pointer arithmetic, and the hardware range check returns 0 for an out-of-range offset - so zero
@@ -82,14 +132,14 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI>
+template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI, bool SWZ>
 __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int LDA = BM + 4, LDB = BN + 4;                        // [k][row] images (SWZ=false; dgrad weights always)
   constexpr int AL = (BM * 4 + 255) / 256;                         // float4 loads of A per thread per slab
   constexpr int BL = B_KSTRIDED ? (BK * (BN / 4) + 255) / 256 : (BN * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][SWZ ? BM * BK : BK * LDA];    // SWZ: [row][16], XOR-swizzled k-chunks
+  __shared__ __attribute__((aligned(16))) float Bs[2][(B_KSTRIDED || !SWZ) ? BK * LDB : BN * BK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
@@ -188,8 +238,12 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
         const int row = idx >> 2;
         float4 v = ra[i];
         if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
-        float* d = &As[buf][(kq_a * 4) * LDA + row];
-        d[0] = v.x; d[LDA] = v.y; d[2 * LDA] = v.z; d[3 * LDA] = v.w;
+        if (SWZ) {
+          *reinterpret_cast<float4*>(&As[buf][row * BK + ((kq_a ^ swz(row)) * 4)]) = v;
+        } else {
+          float* d = &As[buf][(kq_a * 4) * LDA + row];
+          d[0] = v.x; d[LDA] = v.y; d[2 * LDA] = v.z; d[3 * LDA] = v.w;
+        }
       }
     }
 #pragma unroll
@@ -198,8 +252,12 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       if (!B_KSTRIDED) {
         if (idx < BN * 4) {
           const int row = idx >> 2, kq = idx & 3;
-          float* d = &Bs[buf][(kq * 4) * LDB + row];
-          d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
+          if (SWZ) {
+            *reinterpret_cast<float4*>(&Bs[buf][row * BK + ((kq ^ swz(row)) * 4)]) = rb[i];
+          } else {
+            float* d = &Bs[buf][(kq * 4) * LDB + row];
+            d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
+          }
         }
       } else {
         if (idx < BK * (BN / 4)) {
@@ -223,7 +281,8 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   for (int s = s_begin; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
     if (more) { advance(); load_slab(); }
-    mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
+    if (SWZ) mma_slab_sw<MT, NT, B_KSTRIDED>(As[buf], Bs[buf], LDB, wrow, wcol, l16, g, acc);
+    else mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
     if (more) store_slab(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -469,23 +528,38 @@ int profile_read(double* ms, double* flops, int* launches) {
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
-int pick_split_k(long tiles, long kslabs) {
-  // 256 CUs x 3 resident workgroups = 768 slots; aim for >= 4 rounds so the last partial round
-  // costs little, but keep at least 8 slabs (128 of K) per split
-  if (tiles >= 1536) return 1;
-  long want = (3072 + tiles - 1) / tiles;
-  long cap = kslabs / 8;
+int pick_split_k(long tiles, long kslabs, int slots) {
+  // `slots` = workgroups resident on the chip at once (256 CUs x blocks/CU).  The grid runs in
+  // ceil(blocks / slots) rounds; a last round that is mostly empty wastes up to one round, so among
+  // the splits that give >= ~3 rounds pick the one whose last round is fullest (ties: fewer splits).
+  if (tiles >= 6L * slots) return 1;
+  long cap = kslabs / 8;                 // keep >= 8 slabs (128 of K) per split
   if (cap < 1) cap = 1;
-  if (want > cap) want = cap;
-  if (want > 128) want = 128;
-  return (int)(want < 1 ? 1 : want);
+  if (cap > 128) cap = 128;
+  long lo = (2L * slots + tiles - 1) / tiles, hi = (5L * slots + tiles - 1) / tiles;
+  if (lo < 1) lo = 1;
+  if (lo > cap) lo = cap;
+  if (hi > cap) hi = cap;
+  int best = (int)lo;
+  double best_eff = -1;
+  for (long sp = lo; sp <= hi; ++sp) {
+    const double rounds = (double)(tiles * sp) / slots;
+    const double eff = rounds / (double)((long)(rounds + 0.999999));
+    if (eff > best_eff + 0.02) { best_eff = eff; best = (int)sp; }
+  }
+  return best;
 }
+
+int g_variant = 0;      // A/B switch for in-process kernel comparisons (rdm_debug_variant)
 
 template <int MT, int NT, int WM, int WN, bool TAPS, bool BK_, int EPI>
 static void launch_fwd_cfg(const FwdArgs& a, int split, hipStream_t s) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), split);
-  hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI>), grid, dim3(256), 0, s, a);
+  // shipped: [k][row] LDS image (in-process A/B on MI355X: 104 vs 88 TFLOP/s on the e2 3x3 forward, equal elsewhere);
+  // variant 1: XOR-swizzled [row][16] image with b128 accesses
+  if (g_variant == 1) hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, false>), grid, dim3(256), 0, s, a);
 }
 
 template <bool TAPS, bool BK_, int EPI>
@@ -513,7 +587,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   if (a.N % 96 == 0 && (t1 >= 512 || a.M <= 128)) cfg = 1;
   if (a.M <= 64) cfg = 2;
   const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : (long)cdiv(a.M, 64) * cdiv(a.N, 96);
-  int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs);
+  int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs, 256 * 4);
   if (epi == EPI_STORE_STATS || epi == EPI_MASK_STATS) split = 1;
   if (epi == EPI_STORE && a.bias != nullptr) split = 1;
   if (split > 1) {   // split-K: f32 atomics into a zeroed (possibly strided) output slice
@@ -568,7 +642,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
-  if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs);
+  if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs, 256 * 3);
   {
     const long gb = ((Mpix - 1) * a.ldg + a.N) * 4, xb = (((long)a.g.B * a.g.H * a.g.W - 1) * a.ldx + a.C) * 4;
     if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }

@@ -79,7 +79,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
-int pick_split_k(long tiles, long kslabs);
+int pick_split_k(long tiles, long kslabs, int slots);
 void profile_enable(bool on);
 int profile_read(double* ms, double* flops, int* launches);
 
