@@ -42,12 +42,14 @@ int rdm_version(void);
 
 /* Per-launch HIP-event timing of the MFMA conv kernels (bench.py's roofline leg).  While enabled,
  * every conv launch is bracketed by events on its own stream; rdm_profile_read() synchronises on
- * them (HOST sync - never call it inside a graph capture), returns the summed kernel time (ms),
- * the FLOPs those launches executed and their count, and clears the record. */
+ * them (HOST sync - never call it inside a graph capture), returns the summed kernel time (ms), the
+ * length of the UNION of the kernels' intervals (weight-gradient kernels overlap the dgrad chain on the
+ * library's side stream, so the sum over-counts), the FLOPs the launches executed and their count,
+ * and clears the record. */
 void rdm_profile_enable(int32_t on);
+int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
 /* development switch between kernel variants for in-process A/B timing (0 = shipped) */
 void rdm_debug_variant(int32_t v);
-int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM).  Replaces the nn.Conv2d / torchvision

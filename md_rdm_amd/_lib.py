@@ -24,7 +24,7 @@ _SIGNATURES = {
     "rdm_version": (C.c_int, []),
     "rdm_profile_enable": (None, [i32]),
     "rdm_debug_variant": (None, [i32]),
-    "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
+    "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),

@@ -36,9 +36,9 @@ int rdm_version(void) { return 100; }
 
 void rdm_debug_variant(int32_t v) { rdm::g_variant = v; }
 void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
-int rdm_profile_read(double* conv_ms, double* conv_flops, int32_t* launches) {
+int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches) {
   int n = 0;
-  int rc = profile_read(conv_ms, conv_flops, &n);
+  int rc = profile_read(conv_ms_sum, conv_ms_union, conv_flops, &n);
   if (launches) *launches = n;
   return rc;
 }

@@ -58,8 +58,19 @@ __global__ __launch_bounds__(256) void k_colreduce(float* V, int ldv, const floa
   }
 }
 
+// rows per workgroup: small matrices (split-K layers) get short row chunks so the reduction still
+// spreads over a few hundred workgroups instead of a handful of long serial loops
+static int rows_per_block(long M, int C) {
+  const long xb = cdiv(C / 4, 64);
+  long rpb = (M * xb + 511) / 512;
+  rpb = (rpb + 15) / 16 * 16;
+  if (rpb < 16) rpb = 16;
+  if (rpb > 256) rpb = 256;
+  return (int)rpb;
+}
+
 int launch_colstats(const float* V, int ldv, int M, int C, double* sum, double* sq, hipStream_t s) {
-  const int rpb = 256;
+  const int rpb = rows_per_block(M, C);
   dim3 grid(cdiv(C / 4, 64), cdiv(M, rpb));
   hipLaunchKernelGGL(k_colreduce<0>, grid, dim3(256), 0, s, const_cast<float*>(V), ldv, nullptr, 0, nullptr, nullptr, M, C, rpb, sum, sq);
   RDM_LAUNCH_OK();
@@ -68,7 +79,7 @@ int launch_colstats(const float* V, int ldv, int M, int C, double* sum, double* 
 
 int launch_mask_stats(float* V, int ldv, const float* X, int ldx, const float* xs, const float* xt, int M, int C, double* s0,
                       double* s1, hipStream_t s) {
-  const int rpb = 256;
+  const int rpb = rows_per_block(M, C);
   dim3 grid(cdiv(C / 4, 64), cdiv(M, rpb));
   hipLaunchKernelGGL(k_colreduce<1>, grid, dim3(256), 0, s, V, ldv, X, ldx, xs, xt, M, C, rpb, s0, s1);
   RDM_LAUNCH_OK();
@@ -292,7 +303,7 @@ int launch_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const
                                  double* s0, double* s1, hipStream_t s) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const long Mp = (long)B * (H + 1) * (W + 1);
-  const int rpb = 256;
+  const int rpb = rows_per_block(Mp, C);
   dim3 grid(cdiv(C / 4, 64), cdiv(Mp, rpb));
   hipLaunchKernelGGL(k_trans_pool_bwd_reduce, grid, dim3(256), 0, s, dP, X, ldx, sc, sh, B, H, W, Ho, Wo, C, rpb, s0, s1);
   RDM_LAUNCH_OK();

@@ -20,6 +20,8 @@
 //    of its block buffer in place), so normalised activations never exist in HBM.
 //  * Epilogues: store (+bias), store + per-channel sum/sum^2 (f64 atomics) for the next
 //    BatchNorm, ReLU-mask + BN-backward reductions for dgrad, f32 atomics for split-K.
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "rdm_common.h"
@@ -508,17 +510,41 @@ struct ProfScope {
 };
 }  // namespace
 
-void profile_enable(bool on) { g_prof.on = on; }
-int profile_read(double* ms, double* flops, int* launches) {
+static hipEvent_t g_prof_base = nullptr;
+void profile_enable(bool on) {
+  if (on && !g_prof.on) {              // common time origin so intervals from different streams can be merged
+    if (!g_prof_base) hipEventCreate(&g_prof_base);
+    hipEventRecord(g_prof_base, nullptr);
+    hipEventSynchronize(g_prof_base);
+  }
+  g_prof.on = on;
+}
+// ms_sum: sum of kernel durations; ms_union: length of the union of their [start,end] intervals
+// (weight-gradient kernels run concurrently on the library's side stream, so the sum over-counts
+// the time the chip spends in these kernels)
+int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches) {
   double t = 0, f = 0;
+  std::vector<std::pair<float, float>> iv;
+  iv.reserve(g_prof.recs.size());
   for (auto& r : g_prof.recs) {
     RDM_HIP_OK(hipEventSynchronize(r.b));
-    float e = 0;
-    RDM_HIP_OK(hipEventElapsedTime(&e, r.a, r.b));
-    t += e; f += r.flops;
+    float a0 = 0, b0 = 0;
+    RDM_HIP_OK(hipEventElapsedTime(&a0, g_prof_base, r.a));
+    RDM_HIP_OK(hipEventElapsedTime(&b0, g_prof_base, r.b));
+    iv.emplace_back(a0, b0);
+    t += b0 - a0; f += r.flops;
     g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
   }
-  if (ms) *ms = t;
+  std::sort(iv.begin(), iv.end());
+  double u = 0; float cs = 0, ce = -1;
+  for (auto& x : iv) {
+    if (ce < 0) { cs = x.first; ce = x.second; }
+    else if (x.first <= ce) { if (x.second > ce) ce = x.second; }
+    else { u += ce - cs; cs = x.first; ce = x.second; }
+  }
+  if (ce >= 0) u += ce - cs;
+  if (ms_sum) *ms_sum = t;
+  if (ms_union) *ms_union = u;
   if (flops) *flops = f;
   if (launches) *launches = (int)g_prof.recs.size();
   g_prof.recs.clear();

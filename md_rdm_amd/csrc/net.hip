@@ -92,7 +92,7 @@ struct Bump {
   template <typename T> size_t take(size_t n) { off = (off + 255) & ~(size_t)255; size_t o = off; off += n * sizeof(T); return o; }
 };
 
-struct LayerWs { size_t Y, statY, bn1, bn2, w2p, bs2, bs1; };   // bs*: backward [sum dz | sum dz*x] f64 slots      // bn*: [scale|shift|mean|rstd] x C floats
+struct LayerWs { size_t Y, statY, bn1, bn2, w2p, bs2, bs1, dw3; };   // bs*: backward [sum dz | sum dz*x] f64 slots      // bn*: [scale|shift|mean|rstd] x C floats
 struct BlockGeom { int H, W, M, ctot, cb; };
 
 }  // namespace
@@ -106,7 +106,25 @@ struct NetImpl {
   std::vector<LayerWs> lws[4];
   size_t transP[3], transBn[3];
   // backward scratch
-  size_t G[4], dZ, dZ1, cA, cB, cC, dP, dW3, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
+  size_t G[4], dZ[2], dZ1, cA, cB, cC, dP, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
+  // weight gradients run on a library-owned side stream, fenced with events against the caller's
+  // stream: wgrad of a layer only depends on tensors that are final when its dgrad chain starts
+  hipStream_t side = nullptr;
+  hipEvent_t ev_go = nullptr, ev_dy = nullptr, ev_dz[2] = {nullptr, nullptr}, ev_side = nullptr;
+  bool dz_busy[2] = {false, false};
+  int ensure_side() {
+    if (side) return 0;
+    RDM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_dy, hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[0], hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[1], hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    return 0;
+  }
+  ~NetImpl() {
+    if (side) { hipStreamDestroy(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); }
+  }
   size_t total;
   int training_saved = 1;
 
@@ -158,8 +176,11 @@ struct NetImpl {
       maxCb = std::max(maxCb, (size_t)bg[b].cb);
     }
     for (int t = 0; t < 3; ++t) maxP = std::max(maxP, (size_t)bg[t + 1].M * kTrans[t].cin);
-    dZ = a.take<float>(maxMC);
+    dZ[0] = a.take<float>(maxMC);
+    dZ[1] = a.take<float>(maxMC);
     dZ1 = a.take<float>(maxMCin);
+    for (int b = 0; b < 4; ++b)
+      for (auto& L : lws[b]) L.dw3 = a.take<float>(9 * (size_t)GROWTH * bg[b].cb);
     // backward reductions: one slot per BatchNorm, zeroed by ONE memset at the start of backward
     bwd_stats_begin = a.take<double>(0);
     for (int b = 0; b < 4; ++b)
@@ -171,7 +192,6 @@ struct NetImpl {
     bwd_stats_end = a.take<double>(0);
     cA = a.take<float>(maxC); cB = a.take<float>(maxC); cC = a.take<float>(maxC);
     dP = a.take<float>(maxP);
-    dW3 = a.take<float>(9 * (size_t)GROWTH * maxCb);
     gE1 = a.take<float>((size_t)M1 * 96);
     dWstem = a.take<float>(96 * 160);
     dL = a.take<float>((size_t)bg[3].M * 192);
@@ -274,32 +294,39 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
   const int training = n.training_saved;
   float* blk = at<float>(ws, n.blk[b]);
   float* G = at<float>(ws, n.G[b]);
-  float* dZ = at<float>(ws, n.dZ);
   float* dZ1 = at<float>(ws, n.dZ1);
   float* cA = at<float>(ws, n.cA); float* cB = at<float>(ws, n.cB); float* cC = at<float>(ws, n.cC);
-  float* dW3 = at<float>(ws, n.dW3);
   int rc;
+  if ((rc = n.ensure_side())) return rc;
+  hipStream_t side = n.side;
   for (int i = kBlocks[b].layers - 1; i >= 0; --i) {
     const LayerIdx& L = reg().layers[b][i];
     const LayerWs& W = n.lws[b][i];
     const int cin = kBlocks[b].cin + i * GROWTH, cb = g.cb;
+    const int par = i & 1;
+    float* dZ = at<float>(ws, n.dZ[par]);
     float* Y = at<float>(ws, W.Y);
     float* bn1 = at<float>(ws, W.bn1);
     float* bn2 = at<float>(ws, W.bn2);
     float* w2p = at<float>(ws, W.w2p);
     const float* go = G + cin;
-    // ---- conv2 (3x3): wgrad ----
+    // the layer's output gradient `go` is final here (all later layers have accumulated into it)
+    RDM_HIP_OK(hipEventRecord(n.ev_go, s));
+    // ---- side stream: conv2 (3x3) wgrad ----
     if (Gr[L.conv2]) {
-      if ((rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, s))) return rc;
+      float* dW3 = at<float>(ws, W.dw3);
+      RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_go, 0));
+      if ((rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
       WgradArgs w{};
       w.g = geom3x3(n.B, g.H, g.W, 1);
       w.G = go; w.ldg = g.ctot; w.N = GROWTH;
       w.Xs = Y; w.ldx = cb; w.C = cb; w.x_scale = bn2; w.x_shift = bn2 + cb;
       w.dW = dW3; w.wtap = (long)GROWTH * cb; w.ldw = cb;
-      if ((rc = launch_conv_wgrad(w, s))) return rc;
-      if ((rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, s))) return rc;
+      if ((rc = launch_conv_wgrad(w, side))) return rc;
+      if ((rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, side))) return rc;
     }
-    // ---- conv2 dgrad -> dZ, gated by relu2, with the norm2 backward reductions ----
+    // ---- main: conv2 dgrad -> dZ[par], gated by relu2, with the norm2 backward reductions ----
+    if (n.dz_busy[par]) { RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_dz[par], 0)); n.dz_busy[par] = false; }   // side wgrad still reading this buffer?
     double* s0 = at<double>(ws, W.bs2);
     double* s1 = s0 + cb;
     FwdArgs d{};
@@ -315,17 +342,21 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
                                    Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, cb, training, s)))
       return rc;
     if ((rc = launch_affine3(dZ, cb, dZ, cb, Y, cb, cA, cB, cC, g.M, cb, false, s))) return rc;    // dZ now holds dY
-    // ---- conv1 (1x1): wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
+    // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
-      if ((rc = zero_f32(F(Gr, L.conv1), (size_t)cb * cin, s))) return rc;
+      RDM_HIP_OK(hipEventRecord(n.ev_dy, s));
+      RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_dy, 0));
+      if ((rc = zero_f32(F(Gr, L.conv1), (size_t)cb * cin, side))) return rc;
       WgradArgs w{};
       w.g = geom1x1(n.B, g.H, g.W);
       w.G = dZ; w.ldg = cb; w.N = cb;
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
-      if ((rc = launch_conv_wgrad(w, s))) return rc;
+      if ((rc = launch_conv_wgrad(w, side))) return rc;
+      RDM_HIP_OK(hipEventRecord(n.ev_dz[par], side));
+      n.dz_busy[par] = true;
     }
-    // ---- conv1 dgrad -> dZ1, gated by relu1, with the norm1 backward reductions ----
+    // ---- main: conv1 dgrad -> dZ1, gated by relu1, with the norm1 backward reductions ----
     s0 = at<double>(ws, W.bs1);
     s1 = s0 + cin;
     FwdArgs e{};
@@ -342,6 +373,10 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
       return rc;
     if ((rc = launch_affine3(G, g.ctot, dZ1, cin, blk, g.ctot, cA, cB, cC, g.M, cin, true, s))) return rc;
   }
+  // join: everything the side stream produced (weight gradients) is ordered before what the caller enqueues next
+  RDM_HIP_OK(hipEventRecord(n.ev_side, side));
+  RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
+  n.dz_busy[0] = n.dz_busy[1] = false;
   return 0;
 }
 
@@ -438,7 +473,7 @@ int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, 
   if (sscanf(name, "P%d", &b) == 1 && b >= 0 && b < 3) { *offset_bytes = n.transP[b]; *numel = (int64_t)n.bg[b + 1].M * kTrans[b].cin; return RDM_OK; }
   if (!strcmp(name, "logits")) { *offset_bytes = n.logits; *numel = (int64_t)n.bg[3].M * 192; return RDM_OK; }
   if (!strcmp(name, "e1")) { *offset_bytes = n.e1; *numel = (int64_t)n.M1 * 96; return RDM_OK; }
-  if (!strcmp(name, "dZ")) { *offset_bytes = n.dZ; *numel = 0; for (int k = 0; k < 4; ++k) *numel = std::max<int64_t>(*numel, (int64_t)n.bg[k].M * n.bg[k].cb); return RDM_OK; }
+  if (!strcmp(name, "dZ")) { *offset_bytes = n.dZ[0]; *numel = 0; for (int k = 0; k < 4; ++k) *numel = std::max<int64_t>(*numel, (int64_t)n.bg[k].M * n.bg[k].cb); return RDM_OK; }
   if (!strcmp(name, "dZ1")) { *offset_bytes = n.dZ1; *numel = 0; for (int k = 0; k < 4; ++k) *numel = std::max<int64_t>(*numel, (int64_t)n.bg[k].M * n.bg[k].ctot); return RDM_OK; }
   set_error("rdm_net_buffer: unknown buffer '%s'", name);
   return RDM_ERR_BAD_ARGUMENT;

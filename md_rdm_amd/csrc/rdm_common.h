@@ -81,6 +81,6 @@ int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 int pick_split_k(long tiles, long kslabs, int slots);
 void profile_enable(bool on);
-int profile_read(double* ms, double* flops, int* launches);
+int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches);
 
 }  // namespace rdm
