@@ -57,6 +57,8 @@ def main():
     from md_rdm_amd import _lib, filler, harness, parallel
     from md_rdm_amd.network.RDM_Net import DepthEstimationNet
     L = _lib.lib()
+    if os.environ.get("RDM_VARIANT"):                     # development A/B switch, 0 = shipped
+        L.rdm_debug_variant(int(os.environ["RDM_VARIANT"]))
 
     model = DepthEstimationNet()
     filler.fill_state_dict(model.state_dict())

@@ -134,7 +134,7 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI, bool SWZ>
+template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI, bool SWZ, bool AFFINE = false>
 __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int LDA = BM + 4, LDB = BN + 4;                        // [k][row] images (SWZ=false; dgrad weights always)
@@ -151,13 +151,14 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   const int ntaps = TAPS ? G.KH * G.KW : 1;
   const int nslab_total = (p.C / BK) * ntaps;
   int s_begin = 0, s_end = nslab_total;
-  if (EPI == EPI_ATOMIC) {
+  if (EPI == EPI_ATOMIC || EPI == EPI_MASK_STATS_ATOMIC) {
     const int per = (nslab_total + (int)gridDim.z - 1) / (int)gridDim.z;
     s_begin = blockIdx.z * per;
     s_end = min(nslab_total, s_begin + per);
     if (s_begin >= s_end) return;
   }
   const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A, p.a_bytes), srdW = make_srd(p.Wt, p.w_bytes);
+  const __amdgpu_buffer_rsrc_t srdA2 = make_srd(AFFINE ? p.A2 : p.A, p.a_bytes);
 
   // ---- per-thread operand bookkeeping, fixed for the whole K loop ----
   const int kq_a = tid & 3;                    // every A load of this thread covers the same k-quad
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   // Raw loads only: nothing below consumes a loaded value, so the loads stay in flight across the
   // MFMA phase of the current slab; BN-ReLU / zero padding are applied when staging into LDS.
   float4 ra[AL], rb[BL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ra2[AFFINE ? AL : 1], rfa = rsc, rfb = rsh, rfc = rsh;
   bool rok[AL];
   auto load_slab = [&]() {
     const int c0 = cur_cs * BK;
@@ -227,8 +229,10 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       }
       rok[i] = ok;
       ra[i] = bld4(srdA, ok ? a_voff[i] + a_uni : OOB);
+      if (AFFINE) ra2[i] = bld4(srdA2, ok ? a_voff[i] + a_uni : OOB);
     }
     if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
+    if (AFFINE) { rfa = ld4(p.aff_a + c0 + kq_a * 4); rfb = ld4(p.aff_b + c0 + kq_a * 4); rfc = ld4(p.aff_c + c0 + kq_a * 4); }
 #pragma unroll
     for (int i = 0; i < BL; ++i) rb[i] = bld4(srdW, b_voff[i] == OOB ? OOB : b_voff[i] + b_uni);
   };
@@ -240,6 +244,12 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
         const int row = idx >> 2;
         float4 v = ra[i];
         if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (AFFINE) {
+          const float4 x = ra2[i];
+          v.x = fmaf(rfa.x, v.x, fmaf(rfb.x, x.x, rfc.x)); v.y = fmaf(rfa.y, v.y, fmaf(rfb.y, x.y, rfc.y));
+          v.z = fmaf(rfa.z, v.z, fmaf(rfb.z, x.z, rfc.z)); v.w = fmaf(rfa.w, v.w, fmaf(rfb.w, x.w, rfc.w));
+          if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (SWZ) {
           *reinterpret_cast<float4*>(&As[buf][row * BK + ((kq_a ^ swz(row)) * 4)]) = v;
         } else {
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
     const bool nok = n < p.N;
     float bias = 0.f, xs = 0.f, xt = 0.f;
     if (EPI == EPI_STORE && p.bias != nullptr && nok) bias = p.bias[n];
-    if (EPI == EPI_MASK_STATS && nok) { xs = p.x_scale[n]; xt = p.x_shift[n]; }
+    if ((EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) && nok) { xs = p.x_scale[n]; xt = p.x_shift[n]; }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -317,13 +327,20 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
             v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
             *dst = v;
             s0 += v; s1 += v * x;
+          } else if (EPI == EPI_MASK_STATS_ATOMIC) {
+            // split-K: the ReLU gate and both BatchNorm-backward reductions are LINEAR in the partial
+            // sum, so every K-split gates and reduces its own partial (sum of gated partials = gated sum)
+            const float x = p.X[(long)m * p.ldx + n];
+            v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
+            if (v != 0.f) atomicAdd(dst, v);
+            s0 += v; s1 += v * x;
           } else {
             atomicAdd(dst, v);
           }
         }
       }
     }
-    if (EPI == EPI_STORE_STATS || EPI == EPI_MASK_STATS) {
+    if (EPI == EPI_STORE_STATS || EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) {
       s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
       s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
       if (g == 0 && nok) {
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
 // wgrad kernel: both operands are read along their row (channel) dimension at a fixed pixel
 // (K = output pixels).  dW[tap][n][c] += sum_m G[m][n] * f(X[pix(m,tap)][c]).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS>
+template <int MT, int NT, int WM, int WN, bool TAPS, bool AFFINE = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -375,14 +392,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   const int s_begin = split * per, s_end = min(nslab_total, s_begin + per);
   if (s_begin >= s_end) return;
   const __amdgpu_buffer_rsrc_t srdG = make_srd(p.G, p.g_bytes), srdX = make_srd(p.Xs, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t srdG2 = make_srd(AFFINE ? p.G2 : p.G, p.g_bytes);
 
   // fixed per thread: k (pixel within the slab) and the float4 column group of each load
   unsigned a_voff[AL];  int a_m[AL];
+  float4 fa[AFFINE ? AL : 1], fb[AFFINE ? AL : 1], fc[AFFINE ? AL : 1], ra2[AFFINE ? AL : 1];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int idx = tid + i * 256;
     const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
     const bool ok = idx < BK * (BM / 4) && n0 + r4 * 4 < p.N;
+    if (AFFINE) {
+      fa[i] = fb[i] = fc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) { fa[i] = ld4(p.aff_a + n0 + r4 * 4); fb[i] = ld4(p.aff_b + n0 + r4 * 4); fc[i] = ld4(p.aff_c + n0 + r4 * 4); }
+    }
     a_m[i] = ok ? s_begin * BK + k : 0x40000000;             // "never < Mpix" for dead lanes
     a_voff[i] = (unsigned)(s_begin * BK + k) * (unsigned)(p.ldg * 4) + (unsigned)((n0 + r4 * 4) * 4);
   }
@@ -414,7 +437,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   auto load_slab = [&]() {
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      ra[i] = bld4(srdG, a_m[i] < Mpix ? a_voff[i] : OOB);
+      const bool okm = a_m[i] < Mpix;
+      ra[i] = bld4(srdG, okm ? a_voff[i] : OOB);
+      if (AFFINE) { ra2[i] = bld4(srdG2, okm ? a_voff[i] : OOB); if (!okm) ra2[i].x = __int_as_float(0x7fc00000); }   // NaN tag = "row beyond M"
       a_m[i] += BK; a_voff[i] += (unsigned)(BK * p.ldg * 4);
     }
 #pragma unroll
@@ -440,7 +465,17 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
       const int idx = tid + i * 256;
       if (idx < BK * (BM / 4)) {
         const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
-        *reinterpret_cast<float4*>(&As[buf][k * LDA + r4 * 4]) = ra[i];
+        float4 v = ra[i];
+        if (AFFINE) {
+          const float4 x = ra2[i];
+          if (x.x != x.x) {                       // pixel beyond M: contributes nothing
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+            v.x = fmaf(fa[i].x, v.x, fmaf(fb[i].x, x.x, fc[i].x)); v.y = fmaf(fa[i].y, v.y, fmaf(fb[i].y, x.y, fc[i].y));
+            v.z = fmaf(fa[i].z, v.z, fmaf(fb[i].z, x.z, fc[i].z)); v.w = fmaf(fa[i].w, v.w, fmaf(fb[i].w, x.w, fc[i].w));
+          }
+        }
+        *reinterpret_cast<float4*>(&As[buf][k * LDA + r4 * 4]) = v;
       }
     }
 #pragma unroll
@@ -584,6 +619,9 @@ static void launch_fwd_cfg(const FwdArgs& a, int split, hipStream_t s) {
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), split);
   // shipped: [k][row] LDS image (in-process A/B on MI355X: 104 vs 88 TFLOP/s on the e2 3x3 forward, equal elsewhere);
   // variant 1: XOR-swizzled [row][16] image with b128 accesses
+  if constexpr (!TAPS && BK_) {
+    if (a.A2 != nullptr) { hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, false, true>), grid, dim3(256), 0, s, a); return; }
+  }
   if (g_variant == 1) hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, false>), grid, dim3(256), 0, s, a);
 }
@@ -603,6 +641,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   RDM_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.Wt & 15) == 0, "conv: operands must be 16-byte aligned");
   RDM_CHECK_ARG(a.g.dir == 1 || (a.g.SH == 1 && a.g.SW == 1), "dgrad gather supports stride 1 only");
   RDM_CHECK_ARG(a.M == a.g.B * a.g.Ho * a.g.Wo, "conv: M (%d) != B*Ho*Wo", a.M);
+  RDM_CHECK_ARG(a.A2 == nullptr || (b_kstrided && a.aff_a && a.aff_b && a.aff_c && a.g.KH == 1 && a.g.KW == 1), "conv: the BN-backward prologue is built for 1x1 dgrad only");
   const bool taps = !(a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 &&
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const long kslabs = (long)(a.C / 16) * (taps ? a.g.KH * a.g.KW : 1);
@@ -614,10 +653,10 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   if (a.M <= 64) cfg = 2;
   const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : (long)cdiv(a.M, 64) * cdiv(a.N, 96);
   int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs, 256 * 4);
-  if (epi == EPI_STORE_STATS || epi == EPI_MASK_STATS) split = 1;
+  if (epi == EPI_STORE_STATS) split = 1;                 // sum of squares is not linear in the K-partials
   if (epi == EPI_STORE && a.bias != nullptr) split = 1;
   if (split > 1) {   // split-K: f32 atomics into a zeroed (possibly strided) output slice
-    epi = EPI_ATOMIC;
+    epi = epi == EPI_MASK_STATS ? EPI_MASK_STATS_ATOMIC : EPI_ATOMIC;
     RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
   }
   a.split_k = split;
@@ -635,6 +674,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     case EPI_STORE: launch_fwd_epi<TAPS_, BKS_, EPI_STORE>(a, cfg, split, s); break;            \
     case EPI_STORE_STATS: launch_fwd_epi<TAPS_, BKS_, EPI_STORE_STATS>(a, cfg, split, s); break; \
     case EPI_MASK_STATS: launch_fwd_epi<TAPS_, BKS_, EPI_MASK_STATS>(a, cfg, split, s); break;  \
+    case EPI_MASK_STATS_ATOMIC: launch_fwd_epi<TAPS_, BKS_, EPI_MASK_STATS_ATOMIC>(a, cfg, split, s); break;  \
     default: launch_fwd_epi<TAPS_, BKS_, EPI_ATOMIC>(a, cfg, split, s); break;                  \
   }
   if (taps) { if (b_kstrided) { RDM_FWD_DISPATCH(true, true) } else { RDM_FWD_DISPATCH(true, false) } }
@@ -653,6 +693,7 @@ static void launch_wgrad_cfg(const WgradArgs& a, bool taps, hipStream_t s) {
   const long padded = (b.n_items + 7) / 8 * 8;               // whole groups of 8 so every (item, tap) pair exists
   dim3 grid((unsigned)(taps ? padded * ntaps : b.n_items));
   if (taps) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(256), 0, s, b);
+  else if (b.G2 != nullptr) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false, true>), grid, dim3(256), 0, s, b);
   else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, b);
 }
 
@@ -661,6 +702,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   RDM_CHECK_ARG(a.N % 4 == 0 && a.C % 4 == 0, "wgrad: N (%d) and C (%d) must be multiples of 4", a.N, a.C);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0, "wgrad: strides must be multiples of 4 floats");
   RDM_CHECK_ARG(((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "wgrad: operands must be 16-byte aligned");
+  RDM_CHECK_ARG(a.G2 == nullptr || (a.aff_a && a.aff_b && a.aff_c && a.g.KH == 1 && a.g.KW == 1), "wgrad: the BN-backward prologue is built for 1x1 convs only");
   const bool taps = !(a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 &&
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const int ntaps = taps ? a.g.KH * a.g.KW : 1;

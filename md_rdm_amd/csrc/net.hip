@@ -20,6 +20,8 @@
 
 namespace rdm {
 
+extern int g_variant;
+
 namespace {
 
 constexpr int GROWTH = 48;
@@ -106,7 +108,7 @@ struct NetImpl {
   std::vector<LayerWs> lws[4];
   size_t transP[3], transBn[3];
   // backward scratch
-  size_t G[4], dZ[2], dZ1, cA, cB, cC, dP, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
+  size_t G[4], dZ[2], dZ1, cA, cB, cC, c2[2], dP, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
   // weight gradients run on a library-owned side stream, fenced with events against the caller's
   // stream: wgrad of a layer only depends on tensors that are final when its dgrad chain starts
   hipStream_t side = nullptr;
@@ -191,6 +193,7 @@ struct NetImpl {
     for (int t = 0; t < 3; ++t) transBs[t] = a.take<double>(2 * (size_t)kTrans[t].cin);
     bwd_stats_end = a.take<double>(0);
     cA = a.take<float>(maxC); cB = a.take<float>(maxC); cC = a.take<float>(maxC);
+    c2[0] = a.take<float>(3 * maxC); c2[1] = a.take<float>(3 * maxC);      // norm2 backward coefficients, double-buffered with dZ
     dP = a.take<float>(maxP);
     gE1 = a.take<float>((size_t)M1 * 96);
     dWstem = a.take<float>(96 * 160);
@@ -335,13 +338,16 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     d.Wt = w2p; d.wtap = (long)GROWTH * cb; d.ldw = cb;
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
-    const bool fuse = fuse_stats(g.M, cb);
-    if ((rc = launch_conv_fwd(d, true, fuse ? EPI_MASK_STATS : EPI_STORE, s)) < 0) return rc;
-    if (!fuse && (rc = launch_mask_stats(dZ, cb, Y, cb, bn2, bn2 + cb, g.M, cb, s0, s1, s))) return rc;
-    if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, cA, cB, cC,
+    if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
+    float* q2 = at<float>(ws, n.c2[par]);
+    float* qa = q2, *qb = q2 + cb, *qc = q2 + 2 * cb;
+    if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, qa, qb, qc,
                                    Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, cb, training, s)))
       return rc;
-    if ((rc = launch_affine3(dZ, cb, dZ, cb, Y, cb, cA, cB, cC, g.M, cb, false, s))) return rc;    // dZ now holds dY
+    // shipped: one elementwise pass dZ := dY.  Variant 2 forms dY inside the conv1 dgrad/wgrad loaders instead
+    // (no extra pass, but the heavier loaders cost the MFMA kernels more: 155 vs 164 img/s in an in-process A/B)
+    const bool materialise = g_variant != 2;
+    if (materialise && (rc = launch_affine3(dZ, cb, dZ, cb, Y, cb, qa, qb, qc, g.M, cb, false, s))) return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
       RDM_HIP_OK(hipEventRecord(n.ev_dy, s));
@@ -350,6 +356,7 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
       WgradArgs w{};
       w.g = geom1x1(n.B, g.H, g.W);
       w.G = dZ; w.ldg = cb; w.N = cb;
+      if (!materialise) { w.G2 = Y; w.aff_a = qa; w.aff_b = qb; w.aff_c = qc; }
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
       if ((rc = launch_conv_wgrad(w, side))) return rc;
@@ -362,12 +369,11 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     FwdArgs e{};
     e.g = geom1x1(n.B, g.H, g.W);
     e.A = dZ; e.lda = cb; e.C = cb;
+    if (!materialise) { e.A2 = Y; e.aff_a = qa; e.aff_b = qb; e.aff_c = qc; }
     e.Wt = F(T, L.conv1); e.wtap = 0; e.ldw = cin;
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
-    const bool fuse1 = fuse_stats(g.M, cin);
-    if ((rc = launch_conv_fwd(e, true, fuse1 ? EPI_MASK_STATS : EPI_STORE, s)) < 0) return rc;
-    if (!fuse1 && (rc = launch_mask_stats(dZ1, cin, blk, g.ctot, bn1, bn1 + cin, g.M, cin, s0, s1, s))) return rc;
+    if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
     if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin, cA, cB, cC,
                                    Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, cin, training, s)))
       return rc;
