@@ -8,9 +8,9 @@
 // (B,256,64,40) CPU label tensor + a per-element Python loop, and runs ALS as ~1400 tiny launches
 // per page.  Here: one coalesced kernel writes the quantised grid (each output element is
 // computed from <= 2 scalars, so the kernel is a pure HBM write stream), and ALS keeps one
-// matrix per workgroup resident in LDS (256x64 f32 = 64 KB of CDNA4's 160 KB) for all
-// iterations - R is read from HBM exactly once (compulsory traffic), every matvec is
-// wavefront-reduced on chip.
+// matrix per workgroup resident on chip (256x64 f32 = 64 KB = 64 VGPRs x 256 threads) for all
+// iterations - R is read from HBM exactly once (compulsory traffic) into REGISTERS (one row per
+// thread), p and q live in LDS, every matvec is wavefront-reduced on chip.
 #include <algorithm>
 
 #include "rdm_common.h"
@@ -95,49 +95,51 @@ __device__ __forceinline__ float block_sum_f(float v, float* sh) {
 
 template <int ROWS, bool F64IN>
 __global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, float* __restrict__ hist, double* __restrict__ sse, int batch, int limit) {
-  constexpr int COLS = 64, LD = 68, Q = ROWS / COLS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* R = smem;                   // [ROWS][LD]
-  float* p = R + ROWS * LD;          // [ROWS]
-  float* q = p + ROWS;               // [COLS]
-  float* red = q + COLS;             // [8]
+  // One matrix per workgroup, one ROW per thread, the row held in 64 VGPRs for all iterations:
+  // R is read from HBM exactly once and never re-read from LDS either; only the two vectors
+  // (p: ROWS floats, q: 64 floats) live in LDS and are read as broadcasts.  Thread t's row is also
+  // exactly the slice R'[t/Q][(t%Q)*64 ...] of the reinterpreted matrix the q-update needs.
+  constexpr int COLS = 64, Q = ROWS / COLS;
+  __shared__ __attribute__((aligned(16))) float p[ROWS];
+  __shared__ __attribute__((aligned(16))) float q[COLS];
+  __shared__ float red[8];
   const int t = threadIdx.x;
   const long mat = blockIdx.x;       // = group * batch + b
   const int group = (int)(mat / batch), b = (int)(mat % batch);
-  // coalesced load of the matrix (read from HBM exactly once)
-  for (int i = t; i < ROWS * COLS; i += ROWS) {
-    float v;
-    if (F64IN) v = (float)static_cast<const double*>(Rin)[mat * ROWS * COLS + i];
-    else v = static_cast<const float*>(Rin)[mat * ROWS * COLS + i];
-    R[(i >> 6) * LD + (i & 63)] = v;
+  float r[COLS];
+  if (F64IN) {
+    const double2* src = reinterpret_cast<const double2*>(static_cast<const double*>(Rin) + (mat * ROWS + t) * COLS);
+#pragma unroll
+    for (int j = 0; j < COLS / 2; ++j) { const double2 v = src[j]; r[2 * j] = (float)v.x; r[2 * j + 1] = (float)v.y; }
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(Rin) + (mat * ROWS + t) * COLS);
+#pragma unroll
+    for (int j = 0; j < COLS / 4; ++j) { const float4 v = src[j]; r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w; }
   }
   p[t] = 1.f;
   if (t < COLS) q[t] = 1.f;
   __syncthreads();
-  const float4* row = reinterpret_cast<const float4*>(R + t * LD);
   float* H = hist + mat * (long)(limit + 1) * ROWS;
   double* S = sse + ((long)group * (limit + 1)) * batch + b;
+  const float4* q4 = reinterpret_cast<const float4*>(q);
+  const float4* pseg = reinterpret_cast<const float4*>(p + (t % Q) * COLS);
   float pi = 1.f;
   for (int it = 0; it <= limit; ++it) {
     if (it > 0) {
-      // p-update
       float qq = 0.f, bi = 0.f;
 #pragma unroll
       for (int c4 = 0; c4 < COLS / 4; ++c4) {
-        const float4 rv = row[c4];
-        const float4 qv = reinterpret_cast<const float4*>(q)[c4];
-        bi += rv.x * qv.x + rv.y * qv.y + rv.z * qv.z + rv.w * qv.w;
+        const float4 qv = q4[c4];
+        bi += r[4 * c4] * qv.x + r[4 * c4 + 1] * qv.y + r[4 * c4 + 2] * qv.z + r[4 * c4 + 3] * qv.w;
         qq += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
       }
       pi = bi * (1.0f / (qq + 0.05f));
     }
-    // residual of the current (p, q) pair
-    float e = 0.f;
+    float e = 0.f;                                  // residual of the current (p, q) pair
 #pragma unroll
     for (int c4 = 0; c4 < COLS / 4; ++c4) {
-      const float4 rv = row[c4];
-      const float4 qv = reinterpret_cast<const float4*>(q)[c4];
-      const float d0 = pi * qv.x - rv.x, d1 = pi * qv.y - rv.y, d2 = pi * qv.z - rv.z, d3 = pi * qv.w - rv.w;
+      const float4 qv = q4[c4];
+      const float d0 = pi * qv.x - r[4 * c4], d1 = pi * qv.y - r[4 * c4 + 1], d2 = pi * qv.z - r[4 * c4 + 2], d3 = pi * qv.w - r[4 * c4 + 3];
       e += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     }
     H[(long)it * ROWS + t] = pi;
@@ -145,16 +147,13 @@ __global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, floa
     if (t == 0) S[(long)it * batch] = (double)etot;
     if (it == limit) break;
     if (it == 0) continue;       // record 0 is the all-ones start; the first q-update follows the first p-update
-    // q-update: thread t owns row t of R == flat elements [t*64, t*64+64) == R'[t/Q][(t%Q)*64 ...]
     p[t] = pi;
     const float pp = block_sum_f<ROWS>(pi * pi, red);      // also orders the p[] writes before the reads below
-    const float* pseg = p + (t % Q) * COLS;
     float part = 0.f;
 #pragma unroll
     for (int c4 = 0; c4 < COLS / 4; ++c4) {
-      const float4 rv = row[c4];
-      const float4 pv = reinterpret_cast<const float4*>(pseg)[c4];
-      part += rv.x * pv.x + rv.y * pv.y + rv.z * pv.z + rv.w * pv.w;
+      const float4 pv = pseg[c4];
+      part += r[4 * c4] * pv.x + r[4 * c4 + 1] * pv.y + r[4 * c4 + 2] * pv.z + r[4 * c4 + 3] * pv.w;
     }
     if (Q == 4) { part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); }
     __syncthreads();                                         // all reads of q[] (this iteration) are done
@@ -260,18 +259,12 @@ int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups,
   int* kstar = reinterpret_cast<int*>(w); w += ((size_t)groups * 4 + 255) & ~(size_t)255;
   float* rmse = reinterpret_cast<float*>(w);
   const int nmat = groups * batch;
-  const size_t lds = (size_t)(rows * 68 + rows + 64 + 8) * sizeof(float);
   if (rows == 256) {
-    if (r_is_f64) {
-      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_als<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_als<256, true>), dim3(nmat), dim3(256), lds, stream, R, hist, sse, batch, limit);
-    } else {
-      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_als<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_als<256, false>), dim3(nmat), dim3(256), lds, stream, R, hist, sse, batch, limit);
-    }
+    if (r_is_f64) hipLaunchKernelGGL((k_als<256, true>), dim3(nmat), dim3(256), 0, stream, R, hist, sse, batch, limit);
+    else hipLaunchKernelGGL((k_als<256, false>), dim3(nmat), dim3(256), 0, stream, R, hist, sse, batch, limit);
   } else {
-    if (r_is_f64) hipLaunchKernelGGL((k_als<64, true>), dim3(nmat), dim3(64), lds, stream, R, hist, sse, batch, limit);
-    else hipLaunchKernelGGL((k_als<64, false>), dim3(nmat), dim3(64), lds, stream, R, hist, sse, batch, limit);
+    if (r_is_f64) hipLaunchKernelGGL((k_als<64, true>), dim3(nmat), dim3(64), 0, stream, R, hist, sse, batch, limit);
+    else hipLaunchKernelGGL((k_als<64, false>), dim3(nmat), dim3(64), 0, stream, R, hist, sse, batch, limit);
   }
   RDM_LAUNCH_OK();
   hipLaunchKernelGGL(k_als_select, dim3(groups), dim3(64), 0, stream, sse, kstar, rmse, batch, limit, (double)batch * rows * cols);

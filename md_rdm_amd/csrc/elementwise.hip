@@ -61,11 +61,14 @@ __global__ __launch_bounds__(256) void k_colreduce(float* V, int ldv, const floa
 // rows per workgroup: small matrices (split-K layers) get short row chunks so the reduction still
 // spreads over a few hundred workgroups instead of a handful of long serial loops
 static int rows_per_block(long M, int C) {
-  const long xb = cdiv(C / 4, 64);
-  long rpb = (M * xb + 511) / 512;
+  // every workgroup ends with one f64 atomic per channel, so the number of ROW chunks is the
+  // contention per address: aim for ~48 chunks (measured: 143 chunks made a 13 MB reduction take
+  // 28 us, atomics-bound), but never fewer than 16 or more than 512 rows per workgroup
+  (void)C;
+  long rpb = (M + 47) / 48;
   rpb = (rpb + 15) / 16 * 16;
   if (rpb < 16) rpb = 16;
-  if (rpb > 256) rpb = 256;
+  if (rpb > 512) rpb = 512;
   return (int)rpb;
 }
 

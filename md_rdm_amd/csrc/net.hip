@@ -243,8 +243,8 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
                                  static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
       return rc;
-    float* w2p = at<float>(ws, W.w2p);
-    if ((rc = launch_pack_w(F(T, L.conv2), w2p, GROWTH, g.cb, 9, GROWTH, s))) return rc;
+    float* w2p = at<float>(ws, W.w2p);            // packed on the side stream at the start of forward
+    if (b == 0 && i == 0) RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
     FwdArgs c{};
     c.g = geom3x3(n.B, g.H, g.W, 1);
     c.A = Y; c.lda = g.cb; c.C = g.cb; c.a_scale = bn2; c.a_shift = bn2 + g.cb;
@@ -516,6 +516,15 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
   n.training_saved = training;
   int rc;
   if (training) RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.stats_begin), 0, n.stats_end - n.stats_begin, s));
+  // the 78 3x3 weights are re-packed to [tap][out][in] once per forward, off the critical path: on the
+  // library's side stream, fenced against the caller's stream on both ends
+  if ((rc = n.ensure_side())) return rc;
+  RDM_HIP_OK(hipEventRecord(n.ev_go, s));
+  RDM_HIP_OK(hipStreamWaitEvent(n.side, n.ev_go, 0));
+  for (int b = 0; b < 4; ++b)
+    for (int i = 0; i < kBlocks[b].layers; ++i)
+      if ((rc = launch_pack_w(F(T, reg().layers[b][i].conv2), at<float>(ws, n.lws[b][i].w2p), GROWTH, n.bg[b].cb, 9, GROWTH, n.side))) return rc;
+  RDM_HIP_OK(hipEventRecord(n.ev_side, n.side));
   // stem: 7x7/s2 conv as im2col + GEMM (K = 147 padded to 160), bias, then 3x3/s2 max-pool
   if ((rc = launch_im2col_stem(x, at<float>(ws, n.patches), n.B, n.H0, n.W0, s))) return rc;
   RDM_HIP_OK(hipMemsetAsync(at<float>(ws, n.stem_wp), 0, 96 * 160 * sizeof(float), s));
