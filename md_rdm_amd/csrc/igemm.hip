@@ -130,6 +130,58 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void conv_epilogue(const FwdArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wrow, int wcol, int l16, int g) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wcol + j * 16 + l16;
+    const bool nok = n < p.N;
+    float bias = 0.f, xs = 0.f, xt = 0.f;
+    if (EPI == EPI_STORE && p.bias != nullptr && nok) bias = p.bias[n];
+    if ((EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) && nok) { xs = p.x_scale[n]; xt = p.x_shift[n]; }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wrow + i * 16 + g * 4 + r;
+        if (nok && m < p.M) {
+          float v = acc[i][j][r];
+          float* dst = p.out + (long)m * p.ldc + n;
+          if (EPI == EPI_STORE) {
+            *dst = v + bias;
+          } else if (EPI == EPI_STORE_STATS) {
+            *dst = v;
+            s0 += v; s1 += v * v;
+          } else if (EPI == EPI_MASK_STATS) {
+            const float x = p.X[(long)m * p.ldx + n];
+            v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
+            *dst = v;
+            s0 += v; s1 += v * x;
+          } else if (EPI == EPI_MASK_STATS_ATOMIC) {
+            // split-K: the ReLU gate and both BatchNorm-backward reductions are LINEAR in the partial
+            // sum, so every K-split gates and reduces its own partial (sum of gated partials = gated sum)
+            const float x = p.X[(long)m * p.ldx + n];
+            v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
+            if (v != 0.f) atomicAdd(dst, v);
+            s0 += v; s1 += v * x;
+          } else {
+            atomicAdd(dst, v);
+          }
+        }
+      }
+    }
+    if (EPI == EPI_STORE_STATS || EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) {
+      s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+      if (g == 0 && nok) {
+        atomicAdd(p.stat0 + n, (double)s0);
+        atomicAdd(p.stat1 + n, (double)s1);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
@@ -300,55 +352,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
     buf ^= 1;
   }
 
-  // ---- epilogue ----
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wcol + j * 16 + l16;
-    const bool nok = n < p.N;
-    float bias = 0.f, xs = 0.f, xt = 0.f;
-    if (EPI == EPI_STORE && p.bias != nullptr && nok) bias = p.bias[n];
-    if ((EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) && nok) { xs = p.x_scale[n]; xt = p.x_shift[n]; }
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wrow + i * 16 + g * 4 + r;
-        if (nok && m < p.M) {
-          float v = acc[i][j][r];
-          float* dst = p.out + (long)m * p.ldc + n;
-          if (EPI == EPI_STORE) {
-            *dst = v + bias;
-          } else if (EPI == EPI_STORE_STATS) {
-            *dst = v;
-            s0 += v; s1 += v * v;
-          } else if (EPI == EPI_MASK_STATS) {
-            const float x = p.X[(long)m * p.ldx + n];
-            v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
-            *dst = v;
-            s0 += v; s1 += v * x;
-          } else if (EPI == EPI_MASK_STATS_ATOMIC) {
-            // split-K: the ReLU gate and both BatchNorm-backward reductions are LINEAR in the partial
-            // sum, so every K-split gates and reduces its own partial (sum of gated partials = gated sum)
-            const float x = p.X[(long)m * p.ldx + n];
-            v = (fmaf(x, xs, xt) > 0.f) ? v : 0.f;
-            if (v != 0.f) atomicAdd(dst, v);
-            s0 += v; s1 += v * x;
-          } else {
-            atomicAdd(dst, v);
-          }
-        }
-      }
-    }
-    if (EPI == EPI_STORE_STATS || EPI == EPI_MASK_STATS || EPI == EPI_MASK_STATS_ATOMIC) {
-      s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
-      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
-      if (g == 0 && nok) {
-        atomicAdd(p.stat0 + n, (double)s0);
-        atomicAdd(p.stat1 + n, (double)s1);
-      }
-    }
-  }
+  conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, wcol, l16, g);
 }
 
 // ---------------------------------------------------------------------------------------------
