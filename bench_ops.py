@@ -35,6 +35,20 @@ def report(name, seconds, nbytes, note):
 def main():
     dev = torch.device("cuda:0")
     B = 16
+    L0 = _lib.lib()
+    # attainable peaks on THIS device (denominators next to the datasheet values)
+    n = 1 << 28                                                     # 1 GiB each way
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    t = timeit(lambda: _lib.check(L0.rdm_microbench_copy(_lib.ptr(a), _lib.ptr(b), n, _lib.stream())), reps=10)
+    report("microbench: float4 stream copy 1 GiB -> 1 GiB", t, 2 * n * 4, "attainable HBM3E rate (read + write)")
+    del a, b
+    sc = torch.empty(4096, device=dev)
+    blocks, iters = 256 * 4, 20000
+    t = timeit(lambda: _lib.check(L0.rdm_microbench_mfma_f32(_lib.ptr(sc), blocks, iters, _lib.stream())), reps=3)
+    tf = blocks * 4 * iters * 12 * 2048 / t / 1e12
+    print(json.dumps({"kernel": "microbench: v_mfma_f32_16x16x4_f32 loop, 4 waves/SIMD, 12 accumulators", "ms": round(t * 1e3, 3),
+                      "achieved_TFLOPs": round(tf, 1), "mfma_peak_TFLOPs": 157.3, "frac": round(tf / 157.3, 4),
+                      "note": "attainable fp32 matrix-core rate at the clock the chip holds"}), flush=True)
     quant = RDM_Net.Quantization()
     # d_10 scale: 128x128 relative map, 64 pages of 16x16
     dn = torch.from_numpy(filler.log_uniform("bo.dn", (B, 1, 128, 128), 0.5, 2.0)).to(dev)

@@ -51,6 +51,11 @@ int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_fl
 /* development switch between kernel variants for in-process A/B timing (0 = shipped) */
 void rdm_debug_variant(int32_t v);
 
+/* Attainable-peak microbenchmarks: float4 stream copy (HBM) and a register-only
+ * v_mfma_f32_16x16x4_f32 loop (blocks x 4 waves x iters x 12 MFMAs of 2048 FLOP). */
+int rdm_microbench_copy(const float* src, float* dst, int64_t n_floats, rdm_stream_t stream);
+int rdm_microbench_mfma_f32(float* scratch, int32_t blocks, int32_t iters, rdm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM).  Replaces the nn.Conv2d / torchvision
  * _DenseLayer / _Transition convolutions of network/RDM_Net.py:144,146-147,524-531 and the WSM
