@@ -342,14 +342,15 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   store_slab(0);
   __syncthreads();
   int buf = 0;
+  const int dbg = p.dbg;
   for (int s = s_begin; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
-    if (more) { advance(); load_slab(); }
+    if (more && !(dbg & 1)) { advance(); load_slab(); }
     if (SWZ) mma_slab_sw<MT, NT, B_KSTRIDED>(As[buf], Bs[buf], LDB, wrow, wcol, l16, g, acc);
     else mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
-    if (more) store_slab(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (more && !(dbg & 2)) store_slab(buf ^ 1);
+    if (!(dbg & 4)) __syncthreads();
+    if (!(dbg & 8)) buf ^= 1;
   }
 
   conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, wcol, l16, g);
@@ -598,15 +599,21 @@ int g_variant = 0;      // A/B switch for in-process kernel comparisons (rdm_deb
 int pick_split_k(long tiles, long kslabs, int slots) {
   // `slots` = workgroups resident on the chip at once (256 CUs x blocks/CU).  The grid runs in
   // ceil(blocks / slots) rounds; a last round that is mostly empty wastes up to one round, so among
-  // the splits that give >= ~3 rounds pick the one whose last round is fullest (ties: fewer splits).
+  // the splits that give between LO and HI rounds pick the one whose last round is fullest (ties: fewer
+  // splits).  Every split pays a prologue (row decode) and an atomic epilogue, so keep >= MINS slabs each.
+  // (MINS, LO, HI) = (16, 1, 3): swept on one MI355X over the B=16 228x304 step - (8, 2, 5) was 7 % slower
+  // (too many short splits on the M=4560 / M=1280 layers), 32 slabs 4 % slower, 64 slabs 16 % slower
+  constexpr int MINS = 16;
+  constexpr double LO = 1.0, HI = 3.0;
   if (tiles >= 6L * slots) return 1;
-  long cap = kslabs / 8;                 // keep >= 8 slabs (128 of K) per split
+  long cap = kslabs / MINS;
   if (cap < 1) cap = 1;
   if (cap > 128) cap = 128;
-  long lo = (2L * slots + tiles - 1) / tiles, hi = (5L * slots + tiles - 1) / tiles;
+  long lo = (long)((LO * slots + tiles - 1) / tiles), hi = (long)((HI * slots + tiles - 1) / tiles);
   if (lo < 1) lo = 1;
   if (lo > cap) lo = cap;
   if (hi > cap) hi = cap;
+  if (hi < lo) hi = lo;
   int best = (int)lo;
   double best_eff = -1;
   for (long sp = lo; sp <= hi; ++sp) {
@@ -616,7 +623,6 @@ int pick_split_k(long tiles, long kslabs, int slots) {
   }
   return best;
 }
-
 
 template <int MT, int NT, int WM, int WN, bool TAPS, bool BK_, int EPI>
 static void launch_fwd_cfg(const FwdArgs& a, int split, hipStream_t s) {
@@ -666,6 +672,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
   }
   a.split_k = split;
+  a.dbg = g_variant >= 16 ? g_variant - 16 : 0;
   {
     const long npix = (long)a.g.B * a.g.H * a.g.W, nt = taps ? a.g.KH * a.g.KW : 1;
     const long ab = ((npix - 1) * a.lda + a.C) * 4;
