@@ -213,7 +213,7 @@ ConvGeom geom3x3(int B, int H, int W, int dir) { return ConvGeom{B, H, W, H, W, 
 
 // statistics of rows of a matrix are fused in the conv epilogue on big layers; split-K layers
 // (few rows) reduce with a separate pass
-inline bool fuse_stats(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536; }
+inline bool fuse_stats(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536; }   // flat between 512 and 3072 (swept)
 
 int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hipStream_t s) {
   const BlockGeom& g = n.bg[b];

@@ -182,3 +182,49 @@ def test_full_size_properties_b16_228x304(dev):
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), n
     assert dict(m.named_parameters())["encoder.conv_e1.weight"].grad.abs().max() > 0
+
+
+def test_state_dict_roundtrip_and_reflatten(dev):
+    """Checkpoints interchange (968 reference keys); .to()/load_state_dict keep the native plan coherent."""
+    a = make_model(dev, train=False)
+    x, _ = filler.synthetic_batch(1, 228, 228, seed=3)
+    xg = torch.from_numpy(x).to(dev)
+    with torch.no_grad():
+        _, da, Pa = a(xg)
+    sd = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    b = DepthEstimationNet()                     # random init, CPU
+    b.load_state_dict(sd)
+    b = b.to(dev).eval()
+    with torch.no_grad():
+        _, db, Pb = b(xg)
+        b.load_state_dict(sd)                    # in-place copy into the flattened parameters
+        b = b.to(dev)                            # no-op move must not detach the flat views
+        _, dc, Pc = b(xg)
+    # split-K f32 atomics make the summation order run-dependent: equal to float32 rounding, not bitwise
+    assert (da != db).sum().item() <= 1 and (da != dc).sum().item() <= 1
+    assert torch.allclose(Pa, Pb, atol=5e-6) and torch.allclose(Pa, Pc, atol=5e-6)
+
+
+def test_several_steps_train_and_guard_against_stale_activations(dev):
+    from md_rdm_amd import _lib, harness
+    m = make_model(dev)
+    m.flatten_parameters()
+    m.direct_grads = True
+    opt = harness.FusedAdamW(m, lr=1e-4)
+    x, y = filler.synthetic_batch(2, 228, 228, seed=21)
+    xg, yg = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss, parts = harness.training_step(m, xg, yg)
+        loss.backward()
+        opt.step()
+        losses.append(parts["ord_loss"].item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]          # the ordinal loss is what trains the convs
+    # a second forward before backward would overwrite the saved activations: must fail loudly, not silently
+    loss, _ = harness.training_step(m, xg, yg)
+    with torch.no_grad():
+        m(xg)
+    with pytest.raises(_lib.RdmError):
+        loss.backward()
