@@ -67,7 +67,6 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   const float* X; int ldx; const float* x_scale; const float* x_shift;  // MASK_STATS: forward pre-BN value + its affine
   int split_k;                                // >1 => EPI_ATOMIC into pre-zeroed out
   unsigned a_bytes, w_bytes;                  // set by the launcher: addressable extents of A / Wt (buffer descriptors)
-  int dbg;                                    // ablation bits (development only)
 };
 
 struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)][c])
