@@ -664,6 +664,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   if (a.N % 96 == 0 && (t1 >= 512 || a.M <= 128)) cfg = 1;
   if (t1 >= 512 && (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N) cfg = 1;      // a ragged last N tile is fine up to 4 % waste (A/B: 110.7 vs 107.6 TF)
   if (a.M <= 64) cfg = 2;
+  // (a 64x96 wave tile - 256x96 block, 2 waves/SIMD - was measured: +1 % on the 1x1 forward, -21 % on the 3x3 dgrad)
   const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : (long)cdiv(a.M, 64) * cdiv(a.N, 96);
   int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs, 256 * 4);
   if (epi == EPI_STORE_STATS) split = 1;                 // sum of squares is not linear in the K-partials
