@@ -167,6 +167,11 @@ int rdm_fine_detail_pred_bwd(const double* levels, const float* dyhat, float* dw
 int rdm_recombine_f64(const float* yhat, double* out, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream);
 int rdm_recombine_bwd(const double* dout, float* dyhat, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream);
 
+/* metrics.py:48-128 (validation metrics) in one pass over the pixels with target > 0 (pred clamped to 1e-7):
+ * out10 = [count, #delta1, #delta2, #delta3, sum sq err, sum abs err, sum |log10 p - log10 t|,
+ *          sum |p-t|/t, sum (p-t)^2/t, sum sqrt((p-t)^2/t)]; the host divides by count (after an all-reduce under DP) */
+int rdm_depth_metrics_f64(const double* pred, const double* target, int64_t n, double* out10, rdm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Relative decoders (dormant in the reference graph, live as operators):
  * ratio grid + Lloyd quantisation (RDM_Net.py:244-311, computations.py:269-295) and rank-1 ALS

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "rdm_fine_detail_pred_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "rdm_recombine_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "rdm_recombine_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_depth_metrics_f64": (C.c_int, [vp, vp, i64, vp, vp]),
     "rdm_ratio_grid_lloyd_dense": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
     "rdm_ratio_grid_lloyd_paged": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "rdm_als_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),

@@ -236,3 +236,47 @@ int rdm_recombine_bwd(const double* dout, float* dyhat, int32_t batch, int32_t n
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Validation metrics of metrics.py:48-128 in ONE pass (the reference runs ~10 masked-select ATen
+// launches per metric): over pixels with target > 0, pred clamped to >= 1e-7,
+//   out = [count, #(maxratio<1.25), #(<1.25^2), #(<1.25^3), sum (p-t)^2, sum |p-t|,
+//          sum |log10 p - log10 t|, sum |p-t|/t, sum (p-t)^2/t, sum sqrt((p-t)^2/t)]
+// ------------------------------------------------------------------------------------------------
+namespace rdm {
+__global__ __launch_bounds__(256) void k_depth_metrics(const double* __restrict__ pred, const double* __restrict__ target, long n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double t = target[i];
+    if (!(t > 0)) continue;
+    const double p = fmax(pred[i], 1e-7);
+    const double r = fmax(p / t, t / p), d = p - t;
+    acc[0] += 1;
+    acc[1] += r < 1.25 ? 1 : 0;
+    acc[2] += r < 1.25 * 1.25 ? 1 : 0;
+    acc[3] += r < 1.25 * 1.25 * 1.25 ? 1 : 0;
+    acc[4] += d * d;
+    acc[5] += fabs(d);
+    acc[6] += fabs(log10(p) - log10(t));
+    acc[7] += fabs(d) / t;
+    acc[8] += d * d / t;
+    acc[9] += sqrt(d * d / t);
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const double r = block_sum_bcast(acc[k], sh);
+    if (threadIdx.x == 0) atomicAdd(out + k, r);
+  }
+}
+}  // namespace rdm
+
+extern "C" int rdm_depth_metrics_f64(const double* pred, const double* target, int64_t n, double* out10, rdm_stream_t stream) {
+  RDM_CHECK_ARG(pred && target && out10 && n > 0, "depth_metrics: bad argument");
+  RDM_HIP_OK(hipMemsetAsync(out10, 0, 10 * sizeof(double), stream));
+  hipLaunchKernelGGL(rdm::k_depth_metrics, dim3((int)std::min<long>(rdm::cdiv(n, 256), 1024)), dim3(256), 0, stream, pred, target, (long)n, out10);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}

@@ -35,13 +35,6 @@ class ReduceLROnPlateau:
                 self.bad = 0
 
 
-def delta1(pred_log, target):
-    """metrics.py delta1 on the recombined log-depth map vs the normalised target."""
-    p = torch.exp(pred_log)
-    r = torch.maximum(p / target, target / p)
-    return (r < 1.25).double().mean().item()
-
-
 def main(argv=None):
     parser = ArgumentParser("Trains mono depth estimation models (MI355X-native stack)")
     parser.add_argument("--seed", default=None, type=int)
@@ -52,7 +45,7 @@ def main(argv=None):
     parser.add_argument("--min_epochs", default=1, type=int)
     parser.add_argument("--max_epochs", default=1, type=int)
     parser.add_argument("--max_steps", default=8, type=int, help="steps per epoch in --synthetic mode")
-    parser.add_argument("--metrics", default=["delta1"], nargs="+")
+    parser.add_argument("--metrics", default=["delta1", "delta2", "delta3", "mse", "mae", "log10", "rmse"], nargs="+")
     parser.add_argument("--worker", default=6, type=int)
     parser.add_argument("--find_learning_rate", action="store_true")
     parser.add_argument("--detect_anomaly", action="store_true")
@@ -80,12 +73,14 @@ def main(argv=None):
     torch.cuda.set_device(dev)
 
     from . import filler, harness, parallel
+    from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
     model = DepthEstimationNet().to(dev)
     model.flatten_parameters()
     sync = parallel.attach(model)
     opt = harness.FusedAdamW(model, lr=args.learning_rate)
     sched = ReduceLROnPlateau(opt, "max", patience=2)
+    logger = MetricLogger(args.metrics if "delta1" in args.metrics else ["delta1"] + list(args.metrics))
     H, W = args.size
     steps = 1 if args.dev else args.max_steps
     for epoch in range(args.max_epochs):
@@ -106,7 +101,8 @@ def main(argv=None):
         with torch.no_grad():
             x, y = filler.synthetic_batch(1, H, W, seed=99)
             y_hat, y_n = harness.validation_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
-        d1 = delta1(y_hat, y_n)
+        val = logger.log_val(y_hat, y_n)           # the reference compares the (log-domain) recombination with the normalised target as is (module.py:117)
+        d1 = val["delta1"]
         sched.step(d1)
         if rank == 0:
             print(f"epoch {epoch}: {steps * args.batch_size * world / (time.time() - t0):.1f} img/s, val_delta1 {d1:.4f}, lr {opt.lr:g}", flush=True)

@@ -112,3 +112,23 @@ def test_model_surface_on_cpu():
     assert not any(p.requires_grad for p in m.encoder.parameters())
     with pytest.raises(_lib.RdmError):
         m(torch.zeros(1, 3, 228, 228))          # no CPU fallback
+
+
+def test_lightning_checkpoint_wire_format(tmp_path):
+    """model.<key> prefix of the reference's LightningModule (module.py:32, train.py:41-47), both directions."""
+    import torch
+    from md_rdm_amd import checkpoint, filler
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    a = DepthEstimationNet()
+    filler.fill_state_dict(a.state_dict())
+    ck = checkpoint.to_lightning(a)
+    assert len(ck["state_dict"]) == 968 and all(k.startswith("model.") for k in ck["state_dict"])
+    assert "model.encoder.dense_e2.denselayer1.norm1.weight" in ck["state_dict"]
+    path = tmp_path / "last.ckpt"
+    torch.save(ck, path)
+    b = DepthEstimationNet()
+    res = checkpoint.from_lightning(b, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    checkpoint.from_lightning(b, a.state_dict())        # a bare state_dict is accepted too

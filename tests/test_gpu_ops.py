@@ -243,3 +243,21 @@ def test_als_full_size_properties(env):
     out = cp.als_pages((u * v).contiguous(), limit=100).view(16, 256)
     ratio = out / u.view(16, 256)
     np.testing.assert_allclose((ratio / ratio[:, :1]).cpu().numpy(), 1.0, rtol=2e-4)
+
+
+def test_validation_metrics_fused(env):
+    """metrics.py:48-128 in one pass vs a numpy restatement (masked to target > 0, pred clamped to 1e-7)."""
+    from md_rdm_amd.metrics import MetricComputation
+    pred = U("met.p", (4, 1, 128, 128), -0.5, 3.0).astype(np.float64)
+    tgt = LU("met.t", (4, 1, 128, 128), 0.2, 4.0).astype(np.float64)
+    tgt.flat[::7] = 0.0
+    names = ["delta1", "delta2", "delta3", "mse", "mae", "log10", "absrel", "sqrel", "rmse"]
+    mc = MetricComputation(names)
+    got = mc.compute(g(pred, env), g(tgt, env))
+    m = tgt > 0
+    p, t = np.maximum(pred, 1e-7)[m], tgt[m]
+    r = np.maximum(p / t, t / p)
+    want = [(r < 1.25).mean(), (r < 1.25 ** 2).mean(), (r < 1.25 ** 3).mean(), ((p - t) ** 2).mean(), np.abs(p - t).mean(),
+            np.abs(np.log10(p) - np.log10(t)).mean(), (np.abs(p - t) / t).mean(), ((p - t) ** 2 / t).mean(), np.sqrt((p - t) ** 2 / t).mean()]
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    assert mc.avg("delta1") == got[0] and mc.count == 1
