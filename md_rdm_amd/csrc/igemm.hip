@@ -358,6 +358,155 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 forward with an LDS HALO tile (the live DenseNet 3x3: 48 outputs, K = 9*Cb).
+// A workgroup owns 256 consecutive output pixels (linear NHWC index) x 48 channels.  Per 16-channel
+// slab it stages ONE halo run of 256 + 2*(W+1) pixels - BN scale/shift + ReLU applied once per
+// element - and the 9 filter taps read their A fragments from that run at offset r*W + q; border /
+// batch wrap-around is undone per (row, tap) with a 9-bit validity mask held in registers.  Versus the
+// generic kernel that re-gathers, re-normalises and re-stages the tile for every tap this is 5.6x
+// fewer global loads, BN-ReLU VALU ops and LDS stores per MFMA.  Weights are staged per tap
+// (double-buffered, one barrier per tap).  Needs 2*(W+1) <= 256 (else the launcher uses the generic path).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int HL>                       // HL = float4 halo loads per thread per channel slab = ceil(halo / 64)
+__global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
+  constexpr int MT = 4, NT = 3, BM = 256, BN = 48;
+  constexpr int LDH = HL * 64 + 4;              // halo run of 256 + 2*(W+1) <= HL*64 pixels (+pad)
+  constexpr int LDB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float Ah[BK * LDH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wrow = wave * MT * 16;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const ConvGeom& G = p.g;
+  const int W = G.W, H = G.H;
+  const int halo = BM + 2 * (W + 1);
+  const int ncs = p.C / BK;
+  int cs_begin = 0, cs_end = ncs;
+  if (EPI == EPI_ATOMIC) {
+    const int per = (ncs + (int)gridDim.z - 1) / (int)gridDim.z;
+    cs_begin = blockIdx.z * per;
+    cs_end = min(ncs, cs_begin + per);
+    if (cs_begin >= cs_end) return;
+  }
+  const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A, p.a_bytes), srdW = make_srd(p.Wt, p.w_bytes);
+
+  // ---- validity of every (row, tap) pair for this lane's 4 rows of each of its MT tiles ----
+  unsigned vmask[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wrow + i * 16 + l16;
+    unsigned v = 0;
+    if (m < p.M) {
+      const int hw = H * W;
+      const int rem = m - (m / hw) * hw;
+      const int oy = rem / W, ox = rem - oy * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v |= 1u << t;
+      }
+    }
+    vmask[i] = v;
+  }
+  // ---- halo staging: thread -> (halo pixel h, k-quad) ----
+  const int kq_a = tid & 3;
+  unsigned h_voff[HL];
+  bool h_ok[HL];
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const int hidx = (tid + i * 256) >> 2;                       // halo pixel index 0..halo-1
+    const long pix = (long)m0 - (W + 1) + hidx;
+    h_ok[i] = hidx < halo && pix >= 0 && pix < (long)G.B * H * W;
+    h_voff[i] = (unsigned)pix * (unsigned)(p.lda * 4) + (unsigned)(kq_a * 16);
+  }
+  const bool bnrelu = p.a_scale != nullptr;
+  float4 rh[HL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_halo = [&](int cs) {
+    const unsigned uni = (unsigned)(cs * BK * 4);
+#pragma unroll
+    for (int i = 0; i < HL; ++i) rh[i] = bld4(srdA, h_ok[i] ? h_voff[i] + uni : OOB);
+    if (bnrelu) { rsc = ld4(p.a_scale + cs * BK + kq_a * 4); rsh = ld4(p.a_shift + cs * BK + kq_a * 4); }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int hidx = (tid + i * 256) >> 2;
+      if (hidx < halo) {
+        float4 v = rh[i];
+        if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!h_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+        float* d = &Ah[(kq_a * 4) * LDH + hidx];
+        d[0] = v.x; d[LDH] = v.y; d[2 * LDH] = v.z; d[3 * LDH] = v.w;
+      }
+    }
+  };
+  // ---- weights: 48 rows x 16 k per tap, K-contiguous rows -> [k][row] image ----
+  const int b_row = tid >> 2, b_kq = tid & 3;
+  const bool b_act = tid < BN * 4 && n0 + b_row < p.N;
+  const unsigned b_voff = (unsigned)(n0 + b_row) * (unsigned)(p.ldw * 4) + (unsigned)(b_kq * 16);
+  float4 rb;
+  auto load_b = [&](int cs, int tap) {
+    rb = bld4(srdW, b_act ? b_voff + (unsigned)tap * (unsigned)(p.wtap * 4) + (unsigned)(cs * BK * 4) : OOB);
+  };
+  auto store_b = [&](int buf) {
+    if (tid < BN * 4) {
+      float* d = &Bs[buf][(b_kq * 4) * LDB + b_row];
+      d[0] = rb.x; d[LDB] = rb.y; d[2 * LDB] = rb.z; d[3 * LDB] = rb.w;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_halo(cs_begin);
+  load_b(cs_begin, 0);
+  store_halo();
+  store_b(0);
+  __syncthreads();
+  int buf = 0;
+  for (int cs = cs_begin; cs < cs_end; ++cs) {
+    const bool more_cs = cs + 1 < cs_end;
+    if (more_cs) load_halo(cs + 1);                       // in flight during the 9 taps of this slab
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool more = tap < 8 || more_cs;
+      if (more) load_b(tap < 8 ? cs : cs + 1, tap < 8 ? tap + 1 : 0);
+      const int off = wrow + l16 + (tap / 3) * W + (tap % 3);      // halo index of row (wrow + i*16 + l16) for this tap
+      float a[BK / 4][MT], b[BK / 4][NT];
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        const int k = ks * 4 + g;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float v = Ah[k * LDH + off + i * 16];
+          a[ks][i] = ((vmask[i] >> tap) & 1u) ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[ks][j] = Bs[buf][k * LDB + j * 16 + l16];
+      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+      if (more) store_b(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (more_cs) {                                        // every wave is past its last read of Ah (barrier above)
+      store_halo();
+      __syncthreads();
+    }
+  }
+  conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, 0, l16, g);
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad kernel: both operands are read along their row (channel) dimension at a fixed pixel
 // (K = output pixels).  dW[tap][n][c] += sum_m G[m][n] * f(X[pix(m,tap)][c]).
 // ---------------------------------------------------------------------------------------------
@@ -683,6 +832,33 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   }
   ProfScope prof(s, 2.0 * a.M * a.N * (double)kslabs * 16);
 
+  if (!b_kstrided && g_variant != 7 && taps && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 && a.g.PW == 1 && a.g.dir == 1 &&
+      a.g.H == a.g.Ho && a.g.W == a.g.Wo && 2 * (a.g.W + 1) <= 256 && a.A2 == nullptr &&   // halo <= 512 pixels = 8 float4 per thread
+      (epi == EPI_STORE || epi == EPI_STORE_STATS || epi == EPI_ATOMIC) && (long)a.g.B * a.g.H * a.g.W < (1L << 30)) {
+    // LDS halo kernel: split over channel slabs only (each split keeps whole 9-tap groups)
+    const long tiles_h = (long)cdiv(a.M, 256) * cdiv(a.N, 48);
+    int sp = 1;
+    if (epi != EPI_STORE_STATS && !(epi == EPI_STORE && a.bias)) sp = a.split_k > 0 ? a.split_k : pick_split_k(tiles_h, (long)(a.C / 16) * 9, 256 * 4);
+    if (sp > a.C / 16) sp = a.C / 16;
+    Epilogue e2 = epi;
+    if (sp > 1) {
+      e2 = EPI_ATOMIC;
+      if (epi != EPI_ATOMIC) RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
+    } else if (epi == EPI_ATOMIC) sp = 1;
+    dim3 grid(cdiv(a.N, 48), cdiv(a.M, 256), sp);
+    const int hl = cdiv(256 + 2 * (a.g.W + 1), 64);          // 5 (W <= 31), 6 (<= 63), 7 (<= 95), 8 (<= 127)
+#define RDM_HALO(E_)                                                                                        \
+    if (hl <= 5) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 5>), grid, dim3(256), 0, s, a);                \
+    else if (hl == 6) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 6>), grid, dim3(256), 0, s, a);           \
+    else if (hl == 7) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 7>), grid, dim3(256), 0, s, a);           \
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 8>), grid, dim3(256), 0, s, a);
+    if (e2 == EPI_STORE) { RDM_HALO(EPI_STORE) }
+    else if (e2 == EPI_STORE_STATS) { RDM_HALO(EPI_STORE_STATS) }
+    else { RDM_HALO(EPI_ATOMIC) }
+#undef RDM_HALO
+    RDM_LAUNCH_OK();
+    return 0;
+  }
 #define RDM_FWD_DISPATCH(TAPS_, BKS_)                                                           \
   switch (epi) {                                                                               \
     case EPI_STORE: launch_fwd_epi<TAPS_, BKS_, EPI_STORE>(a, cfg, split, s); break;            \
