@@ -367,8 +367,10 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
 // fewer global loads, BN-ReLU VALU ops and LDS stores per MFMA.  Weights are staged per tap
 // (double-buffered, one barrier per tap).  Needs 2*(W+1) <= 256 (else the launcher uses the generic path).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int HL>                       // HL = float4 halo loads per thread per channel slab = ceil(halo / 64)
+template <int EPI, int HL, bool DGRAD>           // HL = float4 halo loads per thread per channel slab = ceil(halo / 64)
 __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
+  // DGRAD: the same machinery run on the output gradient: dx[m][c] = sum_{tap,n} dy[m + (1-r)*W + (1-q)][n] * w[tap][n][c]
+  // (taps mirrored, weights read along their input-channel rows), epilogue = ReLU gate + BN-backward sums.
   constexpr int MT = 4, NT = 3, BM = 256, BN = 48;
   constexpr int LDH = HL * 64 + 4;              // halo run of 256 + 2*(W+1) <= HL*64 pixels (+pad)
   constexpr int LDB = BN + 4;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
   const int halo = BM + 2 * (W + 1);
   const int ncs = p.C / BK;
   int cs_begin = 0, cs_end = ncs;
-  if (EPI == EPI_ATOMIC) {
+  if (EPI == EPI_ATOMIC || EPI == EPI_MASK_STATS_ATOMIC) {
     const int per = (ncs + (int)gridDim.z - 1) / (int)gridDim.z;
     cs_begin = blockIdx.z * per;
     cs_end = min(ncs, cs_begin + per);
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
   }
   const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A, p.a_bytes), srdW = make_srd(p.Wt, p.w_bytes);
 
-  // ---- validity of every (row, tap) pair for this lane's 4 rows of each of its MT tiles ----
+  // ---- validity of every (row, tap) pair for this lane's row of each of its MT tiles ----
   unsigned vmask[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
       const int oy = rem / W, ox = rem - oy * W;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v |= 1u << t;
+        const int dy = DGRAD ? 1 - t / 3 : t / 3 - 1, dx = DGRAD ? 1 - t % 3 : t % 3 - 1;
+        if ((unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W) v |= 1u << t;
       }
     }
     vmask[i] = v;
@@ -441,18 +443,24 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
       }
     }
   };
-  // ---- weights: 48 rows x 16 k per tap, K-contiguous rows -> [k][row] image ----
-  const int b_row = tid >> 2, b_kq = tid & 3;
-  const bool b_act = tid < BN * 4 && n0 + b_row < p.N;
-  const unsigned b_voff = (unsigned)(n0 + b_row) * (unsigned)(p.ldw * 4) + (unsigned)(b_kq * 16);
+  // ---- weights per tap: forward 48 rows (n) x 16 k read along k; dgrad 16 k (n) x 48 cols (c) read along c ----
+  const int b_row = DGRAD ? tid / 12 : tid >> 2, b_q = DGRAD ? tid % 12 : tid & 3;     // dgrad: (k, float4 column group)
+  const bool b_act = tid < BN * 4 && (DGRAD ? n0 + b_q * 4 < p.N : n0 + b_row < p.N);
+  const unsigned b_voff = DGRAD ? (unsigned)b_row * (unsigned)(p.ldw * 4) + (unsigned)((n0 + b_q * 4) * 4)
+                                : (unsigned)(n0 + b_row) * (unsigned)(p.ldw * 4) + (unsigned)(b_q * 16);
   float4 rb;
   auto load_b = [&](int cs, int tap) {
-    rb = bld4(srdW, b_act ? b_voff + (unsigned)tap * (unsigned)(p.wtap * 4) + (unsigned)(cs * BK * 4) : OOB);
+    const unsigned uni = (unsigned)tap * (unsigned)(p.wtap * 4) + (DGRAD ? (unsigned)(cs * BK) * (unsigned)(p.ldw * 4) : (unsigned)(cs * BK * 4));
+    rb = bld4(srdW, b_act ? b_voff + uni : OOB);
   };
   auto store_b = [&](int buf) {
     if (tid < BN * 4) {
-      float* d = &Bs[buf][(b_kq * 4) * LDB + b_row];
-      d[0] = rb.x; d[LDB] = rb.y; d[2 * LDB] = rb.z; d[3 * LDB] = rb.w;
+      if (DGRAD) {
+        *reinterpret_cast<float4*>(&Bs[buf][b_row * LDB + b_q * 4]) = rb;
+      } else {
+        float* d = &Bs[buf][(b_q * 4) * LDB + b_row];
+        d[0] = rb.x; d[LDB] = rb.y; d[2 * LDB] = rb.z; d[3 * LDB] = rb.w;
+      }
     }
   };
 
@@ -475,7 +483,9 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
     for (int tap = 0; tap < 9; ++tap) {
       const bool more = tap < 8 || more_cs;
       if (more) load_b(tap < 8 ? cs : cs + 1, tap < 8 ? tap + 1 : 0);
-      const int off = wrow + l16 + (tap / 3) * W + (tap % 3);      // halo index of row (wrow + i*16 + l16) for this tap
+      const int r = tap / 3, q = tap - r * 3;
+      // halo index of row (wrow + i*16 + l16) for this tap: halo[0] is pixel m0 - (W+1)
+      const int off = wrow + l16 + (DGRAD ? (2 - r) * W + (2 - q) : r * W + q);
       float a[BK / 4][MT], b[BK / 4][NT];
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
@@ -832,30 +842,31 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   }
   ProfScope prof(s, 2.0 * a.M * a.N * (double)kslabs * 16);
 
-  if (!b_kstrided && g_variant != 7 && taps && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 && a.g.PW == 1 && a.g.dir == 1 &&
+  const bool halo_fwd = !b_kstrided && a.g.dir == 1, halo_dgrad = b_kstrided && a.g.dir == -1;
+  if ((halo_fwd || halo_dgrad) && g_variant != 7 && taps && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 && a.g.PW == 1 &&
       a.g.H == a.g.Ho && a.g.W == a.g.Wo && 2 * (a.g.W + 1) <= 256 && a.A2 == nullptr &&   // halo <= 512 pixels = 8 float4 per thread
-      (epi == EPI_STORE || epi == EPI_STORE_STATS || epi == EPI_ATOMIC) && (long)a.g.B * a.g.H * a.g.W < (1L << 30)) {
-    // LDS halo kernel: split over channel slabs only (each split keeps whole 9-tap groups)
-    const long tiles_h = (long)cdiv(a.M, 256) * cdiv(a.N, 48);
-    int sp = 1;
-    if (epi != EPI_STORE_STATS && !(epi == EPI_STORE && a.bias)) sp = a.split_k > 0 ? a.split_k : pick_split_k(tiles_h, (long)(a.C / 16) * 9, 256 * 4);
+      (long)a.g.B * a.g.H * a.g.W < (1L << 30)) {
+    // LDS halo kernel; K is split over whole channel slabs (a split keeps its 9-tap groups together).
+    // `epi` / `split` were already resolved above (split > 1 => atomic epilogue, output zeroed).
+    int sp = split;
     if (sp > a.C / 16) sp = a.C / 16;
-    Epilogue e2 = epi;
-    if (sp > 1) {
-      e2 = EPI_ATOMIC;
-      if (epi != EPI_ATOMIC) RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
-    } else if (epi == EPI_ATOMIC) sp = 1;
     dim3 grid(cdiv(a.N, 48), cdiv(a.M, 256), sp);
     const int hl = cdiv(256 + 2 * (a.g.W + 1), 64);          // 5 (W <= 31), 6 (<= 63), 7 (<= 95), 8 (<= 127)
-#define RDM_HALO(E_)                                                                                        \
-    if (hl <= 5) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 5>), grid, dim3(256), 0, s, a);                \
-    else if (hl == 6) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 6>), grid, dim3(256), 0, s, a);           \
-    else if (hl == 7) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 7>), grid, dim3(256), 0, s, a);           \
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 8>), grid, dim3(256), 0, s, a);
-    if (e2 == EPI_STORE) { RDM_HALO(EPI_STORE) }
-    else if (e2 == EPI_STORE_STATS) { RDM_HALO(EPI_STORE_STATS) }
-    else { RDM_HALO(EPI_ATOMIC) }
+#define RDM_HALO2(E_, D_)                                                                                       \
+    if (hl <= 5) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 5, D_>), grid, dim3(256), 0, s, a);                \
+    else if (hl == 6) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 6, D_>), grid, dim3(256), 0, s, a);           \
+    else if (hl == 7) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 7, D_>), grid, dim3(256), 0, s, a);           \
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 8, D_>), grid, dim3(256), 0, s, a);
+#define RDM_HALO(E_) if (halo_dgrad) { RDM_HALO2(E_, true) } else { RDM_HALO2(E_, false) }
+    switch (epi) {
+      case EPI_STORE: RDM_HALO(EPI_STORE) break;
+      case EPI_STORE_STATS: RDM_HALO(EPI_STORE_STATS) break;
+      case EPI_MASK_STATS: RDM_HALO(EPI_MASK_STATS) break;
+      case EPI_MASK_STATS_ATOMIC: RDM_HALO(EPI_MASK_STATS_ATOMIC) break;
+      default: RDM_HALO(EPI_ATOMIC) break;
+    }
 #undef RDM_HALO
+#undef RDM_HALO2
     RDM_LAUNCH_OK();
     return 0;
   }
