@@ -828,7 +828,10 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs, 256 * 4);
   if (epi == EPI_STORE_STATS) split = 1;                 // sum of squares is not linear in the K-partials
   if (epi == EPI_STORE && a.bias != nullptr) split = 1;
-  if (split > 1) {   // split-K: f32 atomics into a zeroed (possibly strided) output slice
+  if (a.accumulate) {
+    RDM_CHECK_ARG(epi == EPI_STORE && a.bias == nullptr, "conv: accumulate mode supports the plain epilogue only");
+    epi = EPI_ATOMIC;
+  } else if (split > 1) {   // split-K: f32 atomics into a zeroed (possibly strided) output slice
     epi = epi == EPI_MASK_STATS ? EPI_MASK_STATS_ATOMIC : EPI_ATOMIC;
     RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
   }

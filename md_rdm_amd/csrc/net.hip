@@ -112,7 +112,7 @@ struct NetImpl {
   // weight gradients run on a library-owned side stream, fenced with events against the caller's
   // stream: wgrad of a layer only depends on tensors that are final when its dgrad chain starts
   hipStream_t side = nullptr;
-  hipEvent_t ev_go = nullptr, ev_dy = nullptr, ev_dz[2] = {nullptr, nullptr}, ev_side = nullptr;
+  hipEvent_t ev_go = nullptr, ev_dy = nullptr, ev_dz[2] = {nullptr, nullptr}, ev_side = nullptr, ev_fs[2] = {nullptr, nullptr}, ev_fa[2] = {nullptr, nullptr};
   bool dz_busy[2] = {false, false};
   int ensure_side() {
     if (side) return 0;
@@ -122,10 +122,14 @@ struct NetImpl {
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[0], hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[1], hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+      RDM_HIP_OK(hipEventCreateWithFlags(&ev_fs[i], hipEventDisableTiming));
+      RDM_HIP_OK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming));
+    }
     return 0;
   }
   ~NetImpl() {
-    if (side) { hipStreamDestroy(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); }
+    if (side) { hipStreamDestroy(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
   }
   size_t total;
   int training_saved = 1;
@@ -215,30 +219,76 @@ ConvGeom geom3x3(int B, int H, int W, int dir) { return ConvGeom{B, H, W, H, W, 
 // (few rows) reduce with a separate pass
 inline bool fuse_stats(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536; }   // flat between 512 and 3072 (swept)
 
+// norm1 finalisation of layer i restricted to channels [c_lo, c_hi) of the block buffer
+int finalize_norm1(NetImpl& n, int b, int i, int c_lo, int c_hi, bool count_batch, void* ws, void* const* T, int training, hipStream_t s) {
+  const BlockGeom& g = n.bg[b];
+  const LayerIdx& L = reg().layers[b][i];
+  const int cin = kBlocks[b].cin + i * GROWTH;
+  double* bst = at<double>(ws, n.blkstat[b]);
+  float* bn1 = at<float>(ws, n.lws[b][i].bn1);
+  return launch_bn_finalize(bst + c_lo, bst + g.ctot + c_lo, (double)g.M, F(T, L.bn1.w) + c_lo, F(T, L.bn1.b) + c_lo, F(T, L.bn1.rm) + c_lo,
+                            F(T, L.bn1.rv) + c_lo, count_batch ? static_cast<long long*>(T[L.bn1.nbt]) : nullptr, bn1 + c_lo, bn1 + cin + c_lo,
+                            bn1 + 2 * cin + c_lo, bn1 + 3 * cin + c_lo, c_hi - c_lo, training, s);
+}
+
+// conv1 (1x1) of layer i over the input channels [c_lo, c_hi); accumulate => atomically added into a zeroed Y
+int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, bool fuse, void* ws, void* const* T, hipStream_t s) {
+  const BlockGeom& g = n.bg[b];
+  const LayerIdx& L = reg().layers[b][i];
+  const LayerWs& W = n.lws[b][i];
+  const int cin = kBlocks[b].cin + i * GROWTH;
+  float* bn1 = at<float>(ws, W.bn1);
+  double* sty = at<double>(ws, W.statY);
+  FwdArgs a{};
+  a.g = geom1x1(n.B, g.H, g.W);
+  a.A = at<float>(ws, n.blk[b]) + c_lo; a.lda = g.ctot; a.C = c_hi - c_lo; a.a_scale = bn1 + c_lo; a.a_shift = bn1 + cin + c_lo;
+  a.Wt = F(T, L.conv1) + c_lo; a.wtap = 0; a.ldw = cin;
+  a.out = at<float>(ws, W.Y); a.ldc = g.cb; a.M = g.M; a.N = g.cb;
+  a.stat0 = sty; a.stat1 = sty + g.cb;
+  a.accumulate = accumulate ? 1 : 0;
+  const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
+  return rc < 0 ? rc : 0;
+}
+
 int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hipStream_t s) {
   const BlockGeom& g = n.bg[b];
   float* blk = at<float>(ws, n.blk[b]);
   double* bst = at<double>(ws, n.blkstat[b]);
-  for (int i = 0; i < kBlocks[b].layers; ++i) {
+  const int layers = kBlocks[b].layers;
+  // Small-M blocks (dense_e4, decoder) are a strictly serial chain of short kernels that cannot fill the
+  // chip.  DenseNet structure to the rescue: conv1 of layer i+1 contracts over ALL earlier channels, and
+  // everything except the newest 48 is already final while layer i is still running - so that bulk
+  // ("part A") runs one layer ahead on the side stream, and only the 48-channel remainder ("part B",
+  // 3 K-slabs) stays on the critical path.  Both parts add atomically into a zeroed Y.
+  const bool pipelined = !fuse_stats(g.M, g.cb) && layers > 1 && g_variant != 8;
+  hipStream_t side = n.side;
+  int rc;
+  if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[1], s));        // statistics of the block's input channels are final ("layer -1")
+  for (int i = 0; i < layers; ++i) {
     const LayerIdx& L = reg().layers[b][i];
     const LayerWs& W = n.lws[b][i];
     const int cin = kBlocks[b].cin + i * GROWTH;
     float* Y = at<float>(ws, W.Y);
-    float* bn1 = at<float>(ws, W.bn1);
     float* bn2 = at<float>(ws, W.bn2);
     double* sty = at<double>(ws, W.statY);
-    // norm1 statistics: first cin channels of the block buffer; the [sum | sq] halves are ctot apart
-    int rc = launch_bn_finalize(bst, bst + g.ctot, (double)g.M, F(T, L.bn1.w), F(T, L.bn1.b), F(T, L.bn1.rm), F(T, L.bn1.rv),
-                                static_cast<long long*>(T[L.bn1.nbt]), bn1, bn1 + cin, bn1 + 2 * cin, bn1 + 3 * cin, cin, training, s);
-    if (rc) return rc;
-    FwdArgs a{};
-    a.g = geom1x1(n.B, g.H, g.W);
-    a.A = blk; a.lda = g.ctot; a.C = cin; a.a_scale = bn1; a.a_shift = bn1 + cin;
-    a.Wt = F(T, L.conv1); a.wtap = 0; a.ldw = cin;
-    a.out = Y; a.ldc = g.cb; a.M = g.M; a.N = g.cb;
-    a.stat0 = sty; a.stat1 = sty + g.cb;
+    // ---- side stream: part A of layer i+1 (channels [0, cin), final once layer i-1 has published its statistics) ----
+    if (pipelined && i + 1 < layers) {
+      RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_fs[(i + 1) & 1], 0));                 // recorded at the end of layer i-1
+      RDM_HIP_OK(hipMemsetAsync(at<float>(ws, n.lws[b][i + 1].Y), 0, (size_t)g.M * g.cb * sizeof(float), side));
+      if ((rc = finalize_norm1(n, b, i + 1, 0, cin, true, ws, T, training, side))) return rc;
+      if ((rc = conv1_range(n, b, i + 1, 0, cin, true, false, ws, T, side))) return rc;
+      RDM_HIP_OK(hipEventRecord(n.ev_fa[(i + 1) & 1], side));
+    }
+    // ---- main: conv1 of layer i ----
     const bool fuse = training && fuse_stats(g.M, g.cb);
-    if ((rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
+    if (pipelined && i > 0) {
+      if ((rc = finalize_norm1(n, b, i, cin - GROWTH, cin, false, ws, T, training, s))) return rc;
+      RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_fa[i & 1], 0));
+      if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, true, false, ws, T, s))) return rc;
+    } else {
+      if ((rc = finalize_norm1(n, b, i, 0, cin, true, ws, T, training, s))) return rc;
+      if ((rc = conv1_range(n, b, i, 0, cin, false, fuse, ws, T, s))) return rc;
+    }
     if (training && !fuse && (rc = launch_colstats(Y, g.cb, g.M, g.cb, sty, sty + g.cb, s))) return rc;
     if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
                                  static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
@@ -254,6 +304,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     const bool fuse2 = training && fuse_stats(g.M, GROWTH);
     if ((rc = launch_conv_fwd(c, false, fuse2 ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
     if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
+    if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[i & 1], s));     // layer i's output channels + their statistics are final
   }
   return 0;
 }
