@@ -372,9 +372,12 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
   // DGRAD: the same machinery run on the output gradient: dx[m][c] = sum_{tap,n} dy[m + (1-r)*W + (1-q)][n] * w[tap][n][c]
   // (taps mirrored, weights read along their input-channel rows), epilogue = ReLU gate + BN-backward sums.
   constexpr int MT = 4, NT = 3, BM = 256, BN = 48;
-  constexpr int LDH = HL * 64 + 4;              // halo run of 256 + 2*(W+1) <= HL*64 pixels (+pad)
-  constexpr int LDB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float Ah[BK * LDH];
+  // LDS image [k][pixel]: row stride = 16 mod 32 floats, so the two k-groups of a 32-lane half read disjoint
+  // bank halves; k-quad kq is skewed by 8*kq floats, so the transposing ds_write_b32 of a half-wave
+  // (8 pixels x 4 k-quads) lands on 32 distinct banks too.  (Was stride = 4 mod 32: 2-way conflicts both ways.)
+  constexpr int LDH = HL * 64 + 16;             // halo run of 256 + 2*(W+1) <= HL*64 pixels (+pad)
+  constexpr int LDB = BN;
+  __shared__ __attribute__((aligned(16))) float Ah[BK * LDH + 24];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
       if (hidx < halo) {
         float4 v = rh[i];
         if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!h_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
-        float* d = &Ah[(kq_a * 4) * LDH + hidx];
+        float* d = &Ah[(kq_a * 4) * LDH + kq_a * 8 + hidx];
         d[0] = v.x; d[LDH] = v.y; d[2 * LDH] = v.z; d[3 * LDH] = v.w;
       }
     }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
         const int k = ks * 4 + g;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const float v = Ah[k * LDH + off + i * 16];
+          const float v = Ah[k * LDH + ks * 8 + off + i * 16];
           a[ks][i] = ((vmask[i] >> tap) & 1u) ? v : 0.f;
         }
 #pragma unroll
@@ -685,6 +688,183 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
         const int n = n0 + wrow + i * 16 + g * 4 + r;
         if (c < p.C && n < p.N) atomicAdd(base + (long)n * p.ldw + c, acc[i][j][r]);
       }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad of a 3x3 / stride 1 / pad 1 conv: one block owns a whole kernel ROW (3 taps) of a 48 x 256
+// weight tile.  The three taps of a row contract the same gradient pixels against activation
+// pixels that are ONE pixel apart, so the activation slab is staged once (18 pixel rows serve
+// 3 x 16) instead of three times, and its BN-ReLU is applied once.  The activation pixels live in
+// a 48-row LDS ring (3 chunks of 16): slab t reads ring rows 16t .. 16t+17 while chunk t+2 lands.
+// Zero padding is applied on the (small) gradient operand instead of the activations: a per-pixel
+// 3-bit mask (tap q's shifted pixel inside the image?) is staged next to the gradient slab and ANDed
+// into the A fragments - so the activation ring can hold whatever linear neighbour is in memory.
+// LDS strides are 16 mod 32 floats: the four k-groups of a fragment read hit disjoint bank halves
+// (SQ_LDS_BANK_CONFLICT = 0; the generic kernel spends 38 % of its LDS cycles in conflicts).
+// 144 accumulator VGPRs per wave -> 2 waves/SIMD; the fragment fetch is software-pipelined by hand.
+// Measured on the dense_e2 conv2 (M 69312, C 2736, N 48): 1.57 ms / 104.7 TFLOP/s vs 1.74 ms / 94.1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
+  constexpr int WAVES = 4;
+  constexpr int MT = 3, NT = 16 / WAVES;              // wave tile 48 (n) x 64 (c), times 3 taps
+  constexpr int XL = 16 / WAVES;                      // activation float4 loads per thread and chunk
+  constexpr int BM = 48, BN = 256, LDA = BM, LDB = BN + 16, RING = 48;
+  __shared__ __attribute__((aligned(16))) float Gs[2][BK * LDA];
+  __shared__ unsigned Ms[2][BK];                      // per gradient pixel: bit q set <=> tap q's shifted pixel is inside the image
+  __shared__ __attribute__((aligned(16))) float Xr[RING * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wcol = wave * NT * 16;
+  const ConvGeom& G = p.g;
+  // the three kernel rows of a work item sit 8 block-ids apart (same XCD, adjacent in time: they read
+  // the same activations shifted by +-W pixels)
+  const long Lb = blockIdx.x, lane8 = Lb & 7, seq = Lb >> 3;
+  const int r = (int)(seq % 3);
+  const long item = lane8 + 8 * (seq / 3);
+  if (item >= p.n_items) return;
+  const int ctiles = (p.C + BN - 1) / BN, ntiles = (p.N + BM - 1) / BM;
+  const int ct = (int)(item % ctiles);
+  const long t2 = item / ctiles;
+  const int nt = (int)(t2 % ntiles), split = (int)(t2 / ntiles);
+  const int c0 = ct * BN, n0 = nt * BM;
+  const int Mpix = G.B * G.H * G.W;
+  const int nslab_total = (Mpix + BK - 1) / BK;
+  const int per = (nslab_total + p.split_k - 1) / p.split_k;
+  const int s_begin = split * per, s_end = min(nslab_total, s_begin + per);
+  if (s_begin >= s_end) return;
+  const int nsl = s_end - s_begin;
+  const int dy = r - 1;
+  const __amdgpu_buffer_rsrc_t srdG = make_srd(p.G, p.g_bytes), srdX = make_srd(p.Xs, p.x_bytes);
+
+  // activation chunk loads: thread -> pixel rows (tid >> 6) + WAVES * i of the chunk, float4 column tid & 63
+  const int xk = tid >> 6, xr4 = tid & 63;
+  const bool xcol_ok = c0 + xr4 * 4 < p.C;
+  const unsigned xcol = (unsigned)((c0 + xr4 * 4) * 4);
+  const bool bnrelu = p.x_scale != nullptr;
+  float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bnrelu && xcol_ok) { bsc = ld4(p.x_scale + c0 + xr4 * 4); bsh = ld4(p.x_shift + c0 + xr4 * 4); }
+  int xpix = s_begin * BK + dy * G.W - 1 + xk;          // linear input pixel of this thread's first row of chunk 0
+  float4 rx[XL];
+  auto load_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int j = xpix + WAVES * i;
+      const bool ok = xcol_ok & (j >= 0) & (j < Mpix);
+      rx[i] = bld4(srdX, ok ? (unsigned)j * (unsigned)(p.ldx * 4) + xcol : OOB);
+    }
+    xpix += BK;
+  };
+  auto store_chunk = [&](int slot) {                     // slot = chunk index mod 3
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      float4 v = rx[i];
+      if (bnrelu) v = bnrelu4(v, bsc, bsh);
+      *reinterpret_cast<float4*>(&Xr[(slot * 16 + xk + WAVES * i) * LDB + xr4 * 4]) = v;
+    }
+  };
+  // gradient slab loads: threads 0..191 -> pixel tid / 12, float4 column tid % 12
+  const bool gthr = tid < BK * (BM / 4);
+  const int gk = tid / (BM / 4), gn4 = tid - gk * (BM / 4);
+  const bool gcol_ok = gthr && n0 + gn4 * 4 < p.N;
+  int gm = s_begin * BK + gk;
+  unsigned gvoff = (unsigned)gm * (unsigned)(p.ldg * 4) + (unsigned)((n0 + gn4 * 4) * 4);
+  int gy, gx;
+  {
+    const int hw = G.H * G.W, rem = gm % hw;
+    gy = rem / G.W; gx = rem - gy * G.W;
+  }
+  float4 rg;
+  unsigned gmask;
+  const int gdx = BK % G.W, gdy = BK / G.W;              // cursor step of one slab
+  auto load_g = [&]() {
+    const bool ok = gcol_ok & (gm < Mpix);
+    rg = bld4(srdG, ok ? gvoff : OOB);
+    const bool row_ok = (unsigned)(gy + dy) < (unsigned)G.H;
+    gmask = row_ok ? (gx >= 1 ? 1u : 0u) | 2u | (gx + 1 < G.W ? 4u : 0u) : 0u;
+    gm += BK; gvoff += (unsigned)(BK * p.ldg * 4);
+    gx += gdx; gy += gdy;
+    if (gx >= G.W) { gx -= G.W; ++gy; }
+    gy %= G.H;
+  };
+  auto store_g = [&](int buf) {
+    if (gthr) {
+      *reinterpret_cast<float4*>(&Gs[buf][gk * LDA + gn4 * 4]) = rg;
+      if (gn4 == 0) Ms[buf][gk] = gmask;
+    }
+  };
+
+  f32x4 acc[3][MT][NT];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(); store_chunk(0);
+  load_chunk(); store_chunk(1);
+  load_g(); store_g(0);
+  __syncthreads();
+  int buf = 0, slot = 0;                                // slot = t mod 3
+  for (int t = 0; t < nsl; ++t) {
+    const bool more = t + 1 < nsl;
+    if (more) { load_chunk(); load_g(); }
+    const int rb = slot * 16;
+    // fragments of k-step ks+1 are fetched under the MFMAs of k-step ks (explicit two-deep register pipeline;
+    // left alone, the scheduler sinks every ds_read next to its first use and the MFMA pipe waits on LDS)
+    float fa[2][3][MT], fb[2][3][NT];
+    auto fetch = [&](int ks, float (&a)[3][MT], float (&b)[3][NT]) {
+      const int k = ks * 4 + g;
+      const unsigned mk = Ms[buf][k];
+      float araw[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) araw[i] = Gs[buf][k * LDA + i * 16 + l16];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned mq = 0u - ((mk >> q) & 1u);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[q][i] = __uint_as_float(__float_as_uint(araw[i]) & mq);
+        int row = rb + k + q;
+        if (row >= RING) row -= RING;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[q][j] = Xr[row * LDB + wcol + j * 16 + l16];
+      }
+    };
+    fetch(0, fa[0], fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      if (ks + 1 < BK / 4) fetch(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][q][i], fb[ks & 1][q][j], acc[q][i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) { store_chunk(slot == 0 ? 2 : slot - 1); store_g(buf ^ 1); }   // chunk t+2 -> slot (t+2) mod 3
+    __syncthreads();
+    buf ^= 1;
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    float* base = p.dW + (long)(r * 3 + q) * p.wtap;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = c0 + wcol + j * 16 + l16;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int n = n0 + i * 16 + g * 4 + rr;
+          if (c < p.C && n < p.N) atomicAdd(base + (long)n * p.ldw + c, acc[q][i][j][rr]);
+        }
+    }
   }
 }
 
@@ -901,6 +1081,23 @@ static void launch_wgrad_cfg(const WgradArgs& a, bool taps, hipStream_t s) {
   else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, b);
 }
 
+// Split-K of the row kernel.  Its 1-D grid deals blocks round-robin over the 8 XCDs in groups of
+// (8 items x 3 kernel rows); an XCD keeps 32 CUs x 2 blocks resident.  A split that fills the CHIP
+// for R rounds can still leave one XCD with R rounds + 1 block (a 50 % tail at R = 2), so the
+// rounds are counted per XCD and the cheapest (rounds x slabs per block) wins.
+static int pick_split_row3(long tiles0, long kslabs) {
+  const long cap = 32 * 2, max_split = std::max(1L, kslabs / 16), overhead = 8;   // overhead: prologue + atomic epilogue, in slab units
+  long best = 1, best_cost = -1;
+  for (long R = 1; R <= 4; ++R) {
+    long split = std::min(max_split, (R * cap / 3) * 8 / tiles0);
+    if (split < 1) split = 1;
+    const long groups = (tiles0 * split + 7) / 8, rounds = (3 * groups + cap - 1) / cap;
+    const long cost = rounds * ((kslabs + split - 1) / split + overhead);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = split; }
+  }
+  return (int)best;
+}
+
 int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   WgradArgs a = a_in;
   RDM_CHECK_ARG(a.N % 4 == 0 && a.C % 4 == 0, "wgrad: N (%d) and C (%d) must be multiples of 4", a.N, a.C);
@@ -914,14 +1111,22 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
-  if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs, 256 * 3);
+  // 3x3 / stride 1 / pad 1 with few output channels: the row kernel (3 taps per block)
+  const bool row3 = g_variant != 9 && kslabs >= 1024 && a.N <= 96 &&   // long K only: at M <= 4560 the generic kernel's finer tiles win (A/B)
+                    a.G2 == nullptr && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
+                    a.g.PW == 1 && a.g.H == a.g.Ho && a.g.W == a.g.Wo && a.g.dir == 1;
+  if (a.split_k <= 0) a.split_k = row3 ? pick_split_row3((long)cdiv(a.C, 256) * cdiv(a.N, 48), kslabs) : pick_split_k(tiles, kslabs, 256 * 3);
   {
     const long gb = ((Mpix - 1) * a.ldg + a.N) * 4, xb = (((long)a.g.B * a.g.H * a.g.W - 1) * a.ldx + a.C) * 4;
     if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
     a.g_bytes = (unsigned)gb; a.x_bytes = (unsigned)xb;
   }
   ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
-  if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
+  if (row3) {
+    a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
+    const long padded = (a.n_items + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv_wgrad3_row_kernel, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
+  } else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
   else launch_wgrad_cfg<4, 3, 2, 2>(a, taps, s);          // 128 x 96
   RDM_LAUNCH_OK();
   return 0;
