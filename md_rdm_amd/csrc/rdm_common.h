@@ -66,6 +66,7 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   double* stat0; double* stat1;               // STORE_STATS: sum v, sum v^2;  MASK_STATS: sum dz, sum dz*x
   const float* X; int ldx; const float* x_scale; const float* x_shift;  // MASK_STATS: forward pre-BN value + its affine
   int split_k;                                // >1 => EPI_ATOMIC into pre-zeroed out
+  int xcd_flat;                               // 1: keep the hardware block order (A/B switch; default 0 = XCD-aware order)
   int accumulate;                             // 1: add into `out` (f32 atomics), never zero it - the caller owns the initial value
   unsigned a_bytes, w_bytes;                  // set by the launcher: addressable extents of A / Wt (buffer descriptors)
 };
@@ -80,6 +81,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
   int split_k;
   long n_items;                               // set by the launcher: column tiles x row tiles x splits
   unsigned g_bytes, x_bytes;                  // set by the launcher: addressable extents of G / Xs
+  int xcd_flat;                               // 1: keep the hardware block order (A/B switch)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);
