@@ -117,10 +117,28 @@ def main():
         L.rdm_profile_enable(0)
         h = model._plan(B, H, W)[0]
         algo = (L.rdm_net_forward_flops(h) + L.rdm_net_backward_flops(h)) * args.steps   # reference-algorithmic conv FLOPs
-        achieved = algo / (ms.value * 1e-3) / 1e12
         peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
+        achieved = algo / (ms.value * 1e-3) / 1e12
+        per_kernel = []
+        for kind in range(7):
+            nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
+            _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
+            if kn.value:
+                per_kernel.append({"kernel": nm.value.decode(), "launches_per_step": kn.value // max(args.steps, 1),
+                                   "avg_launch_us": round(kms.value / kn.value * 1e3, 1), "ms_sum_per_step": round(kms.value / args.steps, 3),
+                                   "tflops": round(kfl.value / (kms.value * 1e-3) / 1e12, 1), "frac": round(kfl.value / (kms.value * 1e-3) / 1e12 / peak, 3)})
+        per_kernel.sort(key=lambda r: -r["ms_sum_per_step"])
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and (B, H, W) == (16, 228, 304):     # PMC passes cannot run inside this process: measured figure of the same workload
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj["conv_kernels"]["bytes_per_launch"]
+            traffic_src = ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 "
+                           "correction, checked on k_adamw), conv kernels, bytes per launch averaged over one step")
         roof = {"bound": "mfma", "kernel": "conv_fwd_kernel/conv_wgrad_kernel (fp32 MFMA 16x16x4 implicit GEMM)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "per_kernel": per_kernel,
                 "launches_per_step": n.value // max(args.steps, 1), "kernel_ms_per_step": round(ms.value / args.steps, 3),
                 "kernel_ms_sum_per_step": round(ms_sum.value / args.steps, 3),
                 "timing": "HIP events on the launch streams over K further steps run right after the timed region; kernel_ms = union of the conv kernels' intervals (wgrad kernels overlap the dgrad chain on a side stream)",

@@ -48,6 +48,9 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..6 (returns RDM_ERR_ARG beyond), *name = static
+ * string naming the kernel, summed duration (ms), executed FLOPs and launch count of that kernel. */
+int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* development switch between kernel variants for in-process A/B timing (0 = shipped) */
 void rdm_debug_variant(int32_t v);
 

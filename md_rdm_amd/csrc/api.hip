@@ -43,6 +43,13 @@ int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_fl
   return rc;
 }
 
+int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches) {
+  int n = 0;
+  int rc = profile_kind(kind, name, ms_sum, flops, &n);
+  if (launches) *launches = n;
+  return rc;
+}
+
 int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
                    float* y, double* stat_sum, double* stat_sq, rdm_stream_t stream) {
   ConvGeom g;

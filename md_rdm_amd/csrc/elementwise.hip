@@ -187,6 +187,67 @@ int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x
   return 0;
 }
 
+// BN backward in ONE pass: the coefficient computation of k_bn_bwd_coeffs is done per thread for its
+// four channels (a thread keeps its channel group and walks rows), then dst (=|+=) A*dz + B*x + Cc.
+// Removes a 4-us dependent launch from every BatchNorm of the backward chain (156 per step) - and with
+// it the stall of a tiny kernel queued behind the side stream's long-running wgrad blocks.
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0,
+                                                      const double* s1, double count, const float* gamma, const float* mean,
+                                                      const float* rstd, float* dgamma, float* dbeta, int M, int C4, int rows_per_block,
+                                                      int training) {
+  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c4 >= C4) return;
+  const int c = c4 * 4, rsub = threadIdx.x >> 6;
+  float a[4], b[4], cc[4], dg[4], db[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double mu = mean[c + j], rs = rstd[c + j], g = gamma[c + j];
+    const double sdz = s0[c + j], sdzx = s1[c + j];
+    const double sdzxhat = rs * (sdzx - mu * sdz);
+    dg[j] = (float)sdzxhat; db[j] = (float)sdz;
+    const double aa = g * rs;
+    if (training) {
+      const double m1 = sdz / count, m2 = sdzxhat / count;
+      const double bb = -aa * rs * m2;
+      a[j] = (float)aa; b[j] = (float)bb; cc[j] = (float)(-aa * m1 - bb * mu);
+    } else {
+      a[j] = (float)aa; b[j] = 0.f; cc[j] = 0.f;
+    }
+  }
+  if (blockIdx.y == 0 && rsub == 0) {
+    // scalar stores: parameter-gradient tensors are only 4-byte aligned in general
+    if (dgamma) { dgamma[c] = dg[0]; dgamma[c + 1] = dg[1]; dgamma[c + 2] = dg[2]; dgamma[c + 3] = dg[3]; }
+    if (dbeta) { dbeta[c] = db[0]; dbeta[c + 1] = db[1]; dbeta[c + 2] = db[2]; dbeta[c + 3] = db[3]; }
+  }
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+#pragma unroll 4
+  for (int m = m0 + rsub; m < m1; m += 4) {
+    const float4 z = ld4(dz + (long)m * ldz + c), xv = ld4(x + (long)m * ldx + c);
+    float4 r;
+    r.x = fmaf(a[0], z.x, fmaf(b[0], xv.x, cc[0]));
+    r.y = fmaf(a[1], z.y, fmaf(b[1], xv.y, cc[1]));
+    r.z = fmaf(a[2], z.z, fmaf(b[2], xv.z, cc[2]));
+    r.w = fmaf(a[3], z.w, fmaf(b[3], xv.w, cc[3]));
+    float* d = dst + (long)m * ldd + c;
+    if (ACC) { const float4 o = ld4(d); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+    st4(d, r);
+  }
+}
+
+int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
+                        const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
+                        int training, hipStream_t s) {
+  const int C4 = C / 4, gx = cdiv(C4, 64);
+  int rpb = cdiv(M, std::max(1, 4096 / gx));
+  rpb = std::max(16, (rpb + 3) / 4 * 4);
+  dim3 grid(gx, cdiv(M, rpb));
+  if (accumulate) hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training);
+  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Transition front end (RDM_Net.py:527,529,531-532): ZeroPad2d((0,1,0,1)) -> BN -> ReLU -> 2x2
 // average.  The 1x1 conv is linear, so it is applied AFTER the pooling (4x fewer GEMM rows).

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
 // launch stream around every conv kernel; read back (and summed) by rdm_profile_read().
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
 struct Prof {
   bool on = false;
   std::vector<ProfRec> recs;
@@ -913,10 +913,17 @@ struct Prof {
   }
 } g_prof;
 struct ProfScope {
-  hipStream_t s; double flops; hipEvent_t a{}, b{}; bool on;
+  hipStream_t s; double flops; hipEvent_t a{}, b{}; bool on; int kind = 0;
   ProfScope(hipStream_t s_, double f) : s(s_), flops(f), on(g_prof.on) { if (on) { a = g_prof.get(); b = g_prof.get(); hipEventRecord(a, s); } }
-  ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops}); } }
+  ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind}); } }
 };
+// per-kernel breakdown of the last profile_read()
+constexpr int PROF_KINDS = 7;
+const char* const kProfKindName[PROF_KINDS] = {
+    "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
+    "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel"};
+double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS];
+int g_kind_n[PROF_KINDS];
 }  // namespace
 
 static hipEvent_t g_prof_base = nullptr;
@@ -935,6 +942,7 @@ int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches)
   double t = 0, f = 0;
   std::vector<std::pair<float, float>> iv;
   iv.reserve(g_prof.recs.size());
+  for (int k = 0; k < PROF_KINDS; ++k) { g_kind_ms[k] = 0; g_kind_flops[k] = 0; g_kind_n[k] = 0; }
   for (auto& r : g_prof.recs) {
     RDM_HIP_OK(hipEventSynchronize(r.b));
     float a0 = 0, b0 = 0;
@@ -942,6 +950,7 @@ int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches)
     RDM_HIP_OK(hipEventElapsedTime(&b0, g_prof_base, r.b));
     iv.emplace_back(a0, b0);
     t += b0 - a0; f += r.flops;
+    g_kind_ms[r.kind] += b0 - a0; g_kind_flops[r.kind] += r.flops; g_kind_n[r.kind] += 1;
     g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
   }
   std::sort(iv.begin(), iv.end());
@@ -957,6 +966,14 @@ int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches)
   if (flops) *flops = f;
   if (launches) *launches = (int)g_prof.recs.size();
   g_prof.recs.clear();
+  return 0;
+}
+int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int* launches) {
+  RDM_CHECK_ARG(kind >= 0 && kind < PROF_KINDS, "profile_kind: kind %d out of range [0, %d)", kind, PROF_KINDS);
+  if (name) *name = kProfKindName[kind];
+  if (ms_sum) *ms_sum = g_kind_ms[kind];
+  if (flops) *flops = g_kind_flops[kind];
+  if (launches) *launches = g_kind_n[kind];
   return 0;
 }
 
@@ -1054,11 +1071,13 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
   }
   ProfScope prof(s, 2.0 * a.M * a.N * (double)kslabs * 16);
+  prof.kind = b_kstrided ? 1 : 0;
 
   const bool halo_fwd = !b_kstrided && a.g.dir == 1, halo_dgrad = b_kstrided && a.g.dir == -1;
   if ((halo_fwd || halo_dgrad) && g_variant != 7 && taps && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 && a.g.PW == 1 &&
       a.g.H == a.g.Ho && a.g.W == a.g.Wo && 2 * (a.g.W + 1) <= 256 && a.A2 == nullptr &&   // halo <= 512 pixels = 8 float4 per thread
       (long)a.g.B * a.g.H * a.g.W < (1L << 30)) {
+    prof.kind = halo_dgrad ? 3 : 2;
     // LDS halo kernel; K is split over whole channel slabs (a split keeps its 9-tap groups together).
     // `epi` / `split` were already resolved above (split > 1 => atomic epilogue, output zeroed).
     int sp = split;
@@ -1153,6 +1172,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   }
   a.xcd_flat = g_variant == 11;
   ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
+  prof.kind = row3 ? 6 : taps ? 5 : 4;
   if (row3) {
     a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
     const long padded = (a.n_items + 7) / 8 * 8;

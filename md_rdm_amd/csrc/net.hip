@@ -392,13 +392,16 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
     float* q2 = at<float>(ws, n.c2[par]);
     float* qa = q2, *qb = q2 + cb, *qc = q2 + 2 * cb;
-    if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, qa, qb, qc,
-                                   Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, cb, training, s)))
-      return rc;
-    // shipped: one elementwise pass dZ := dY.  Variant 2 forms dY inside the conv1 dgrad/wgrad loaders instead
-    // (no extra pass, but the heavier loaders cost the MFMA kernels more: 155 vs 164 img/s in an in-process A/B)
+    // shipped: one elementwise pass dZ := dY (coefficients computed in the same kernel).  Variant 2 forms dY inside the
+    // conv1 dgrad/wgrad loaders instead (no extra pass, but the heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
     const bool materialise = g_variant != 2;
-    if (materialise && (rc = launch_affine3(dZ, cb, dZ, cb, Y, cb, qa, qb, qc, g.M, cb, false, s))) return rc;
+    if (materialise) {
+      if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,
+                                    Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s)))
+        return rc;
+    } else if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, qa, qb, qc,
+                                          Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, cb, training, s)))
+      return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
       RDM_HIP_OK(hipEventRecord(n.ev_dy, s));
@@ -425,10 +428,9 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
     if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
-    if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin, cA, cB, cC,
-                                   Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, cin, training, s)))
+    if ((rc = launch_bn_bwd_apply(G, g.ctot, dZ1, cin, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
+                                  Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
       return rc;
-    if ((rc = launch_affine3(G, g.ctot, dZ1, cin, blk, g.ctot, cA, cB, cC, g.M, cin, true, s))) return rc;
   }
   // join: everything the side stream produced (weight gradients) is ordered before what the caller enqueues next
   RDM_HIP_OK(hipEventRecord(n.ev_side, side));

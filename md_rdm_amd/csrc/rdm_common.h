@@ -89,5 +89,6 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 int pick_split_k(long tiles, long kslabs, int slots);
 void profile_enable(bool on);
 int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches);
+int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int* launches);
 
 }  // namespace rdm
