@@ -182,8 +182,40 @@ def cpu_baseline(H, W, batch=2, iters=2):
     for _ in range(iters):
         onet.training_step(sd, xt, y)
     dt = (time.perf_counter() - t0) / iters
-    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} train steps (fwd+losses+bwd, no optimizer) at batch {batch}, {H}x{W}, fp32, after 1 warm-up"}
+    out = {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{iters} train steps (fwd+losses+bwd, no optimizer) at batch {batch}, {H}x{W}, fp32, after 1 warm-up"}
+    out["input_pipeline"] = input_pipeline_baseline(H, W)
+    return out
+
+
+def input_pipeline_baseline(H, W, B=16, seconds=3.0):
+    """SURVEY.md 8(f)1 beside the step: training_preprocess of raw 480x640 NYU frames - the reference's Pillow path
+    (oracle/preprocess_cpu.py: the calls torchvision's transforms forward to) on one host core vs the GPU kernel chain."""
+    import numpy as np
+    from md_rdm_amd.dataloaders import nyu
+    from oracle import preprocess_cpu as P
+    rng = np.random.default_rng(0)
+    raws = [(rng.integers(0, 256, (480, 640, 3)).astype(np.uint8), (rng.random((480, 640)) * 9.5 + 0.5).astype(np.float32)) for _ in range(B)]
+    draws = [nyu.draw_training_params(rng, (480, 640), 250, (H, W)) for _ in range(B)]
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        d = draws[n % B][0]
+        P.pil_training_preprocess(raws[n % B][0], raws[n % B][1], d["s"], d["angle"], d["flip"], d["jitter"], 250, (H, W))
+        n += 1
+    cpu_rate = n / (time.perf_counter() - t0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rgb = torch.from_numpy(np.stack([r for r, _ in raws])).to(dev)
+    dep = torch.from_numpy(np.stack([d for _, d in raws])).to(dev)
+    pre, params = nyu.NyuGpuPreprocessor(250, (H, W)), [p for _, p in draws]
+    pre(rgb, dep, params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        pre(rgb, dep, params)
+    torch.cuda.synchronize()
+    gpu_rate = 20 * B / (time.perf_counter() - t0)
+    return {"cpu_images_per_s_per_core": round(cpu_rate, 1), "gpu_images_per_s": round(gpu_rate, 0), "kind": "reference dependency (Pillow)",
+            "sample": f"{n} frames in {seconds:.0f} s on 1 core; GPU: 20 batches of {B}, inputs resident in HBM"}
 
 
 if __name__ == "__main__":

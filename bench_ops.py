@@ -77,6 +77,25 @@ def main():
     lg = torch.from_numpy(filler.uniform("bo.lg", (B, 180, 8, 10), -2, 3)).to(dev)
     t = timeit(lambda: cp.dorn_ordinal_regression(lg))
     report("dorn_fwd B=16 8x10", t, lg.numel() * 4 + lg.numel() // 2 * 8 + B * 80 * 8, "latency-bound (1.5 MB)")
+    bench_input_pipeline(dev)
+
+
+def bench_input_pipeline(dev, B=16, H=480, W=640):
+    """training_preprocess for a batch of raw NYU frames - GPU kernel chain (the Pillow CPU baseline of the same frames is
+    timed in bench.py's cpu_baseline leg, the only bench code allowed to touch oracle/)."""
+    import numpy as np
+    from md_rdm_amd.dataloaders import nyu
+    rng = np.random.default_rng(0)
+    raws = [(rng.integers(0, 256, (H, W, 3)).astype(np.uint8), (rng.random((H, W)) * 9.5 + 0.5).astype(np.float32)) for _ in range(B)]
+    draws = [nyu.draw_training_params(rng, (H, W)) for _ in range(B)]
+    rgb = torch.from_numpy(np.stack([r for r, _ in raws])).to(dev)
+    dep = torch.from_numpy(np.stack([d for _, d in raws])).to(dev)
+    pre = nyu.NyuGpuPreprocessor()
+    params = [p for _, p in draws]
+    t = timeit(lambda: pre(rgb, dep, params), reps=20)
+    nbytes = B * (H * W * 7 + 228 * 304 * 16)
+    report("nyu training_preprocess B=16 480x640 -> 228x304 (inputs resident in HBM)", t, nbytes,
+           f"{B / t:.0f} images/s; compulsory: read rgb u8 + depth f32, write x (3 planes) + y f32; 13 launches, intermediates stay in L2 / Infinity Cache")
 
 
 if __name__ == "__main__":

@@ -176,6 +176,29 @@ int rdm_recombine_bwd(const double* dout, float* dyhat, int32_t batch, int32_t n
 int rdm_depth_metrics_f64(const double* pred, const double* target, int64_t n, double* out10, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * NYU input pipeline: dataloaders/nyu_dataloader.py:240-272 training_preprocess and
+ * :274-287 validation_preprocess for a whole batch on the GPU, bit-exact with the Pillow arithmetic the
+ * reference reaches through torchvision's PIL transforms.  The random draws of the reference are inputs:
+ * one rdm_nyu_aug per sample, in DEVICE memory (md_rdm_amd/dataloaders/nyu.py fills it).
+ *   rgb (B,in_h,in_w,3) uint8, depth (B,in_h,in_w) float32  ->  x (B,3,out_h,out_w), y (B,1,out_h,out_w) float32
+ *   (resized_h, resized_w) = torchvision Resize(resize) of (in_h, in_w); validation = identity augmentation
+ *   (depth_div 1, rot {65536,0,32768,0,65536,32768}, h2/w2 = resized size, ops -1).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rdm_nyu_aug {
+  float depth_div;      /* s: depth / s (:241-242) */
+  int32_t rot[6];       /* Image.rotate(angle) as Geometry.c affine_fixed 16.16 coefficients a0,a1,a2,a3,a4,a5 (:252-254) */
+  int32_t h2, w2;       /* size after Resize(int(resize * s)) (:256-258) */
+  int32_t top, left;    /* CenterCrop origin in the (h2, w2) image (:260-262) */
+  int32_t flip;         /* hflip (:264-266) */
+  int32_t op[3];        /* ColorJitter order: 0 brightness, 1 contrast, 2 saturation, -1 none (:247) */
+  float factor[3];      /* and the enhancement factors */
+} rdm_nyu_aug;
+size_t rdm_nyu_preprocess_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h, int32_t resized_w, int32_t out_w);
+int rdm_nyu_preprocess(const uint8_t* rgb, const float* depth, const rdm_nyu_aug* aug, int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h,
+                       int32_t resized_w, int32_t out_h, int32_t out_w, float* x, float* y, void* workspace, size_t workspace_bytes,
+                       rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Relative decoders (dormant in the reference graph, live as operators):
  * ratio grid + Lloyd quantisation (RDM_Net.py:244-311, computations.py:269-295) and rank-1 ALS
  * (computations.py:38-85,95-155,175-193), paging (:201-238).

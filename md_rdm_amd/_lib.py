@@ -26,6 +26,8 @@ _SIGNATURES = {
     "rdm_debug_variant": (None, [i32]),
     "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind": (C.c_int, [i32, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
+    "rdm_nyu_preprocess_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "rdm_nyu_preprocess": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "rdm_microbench_copy": (C.c_int, [vp, vp, i64, vp]),
     "rdm_microbench_mfma_f32": (C.c_int, [vp, i32, i32, vp]),
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -50,6 +50,16 @@ int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* fl
   return rc;
 }
 
+size_t rdm_nyu_preprocess_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h, int32_t resized_w, int32_t out_w) {
+  return nyu_preprocess_workspace_bytes(batch, in_h, in_w, resized_h, resized_w, out_w);
+}
+int rdm_nyu_preprocess(const uint8_t* rgb, const float* depth, const rdm_nyu_aug* aug, int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h,
+                       int32_t resized_w, int32_t out_h, int32_t out_w, float* x, float* y, void* workspace, size_t workspace_bytes,
+                       rdm_stream_t stream) {
+  return launch_nyu_preprocess(rgb, depth, aug, batch, in_h, in_w, resized_h, resized_w, out_h, out_w, x, y, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream));
+}
+
 int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
                    float* y, double* stat_sum, double* stat_sq, rdm_stream_t stream) {
   ConvGeom g;

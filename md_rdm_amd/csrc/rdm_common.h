@@ -90,5 +90,8 @@ int pick_split_k(long tiles, long kslabs, int slots);
 void profile_enable(bool on);
 int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches);
 int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int* launches);
+size_t nyu_preprocess_workspace_bytes(int B, int H, int W, int h1, int w1, int out_w);
+int launch_nyu_preprocess(const unsigned char* rgb, const float* depth, const void* aug_dev, int B, int H, int W, int h1, int w1, int oh, int ow,
+                          float* x, float* y, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace rdm

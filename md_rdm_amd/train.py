@@ -1,8 +1,11 @@
 """Counterpart of the reference's ``train.py`` (flags :9-26) on the native stack.  Lightning is not
-used: the step logic is md_rdm_amd/harness.py (restating network/module.py).  Datasets are out of
-scope of the hot path; ``--synthetic`` feeds hash-generated NYU-shaped batches.
+used: the step logic is md_rdm_amd/harness.py (restating network/module.py).  ``--nyu_path DIR`` reads
+raw NYU samples (.h5 / .npz) through md_rdm_amd/dataloaders (module.py:19-27: NYUDataset(..., output_size=
+(226, 226)), shuffle for train) with the PIL augmentation chain on the GPU; ``--synthetic`` feeds
+hash-generated NYU-shaped batches.
 
   python -m md_rdm_amd.train --synthetic --batch_size 16 --max_steps 20
+  python -m md_rdm_amd.train --nyu_path /data/nyudepthv2 --batch_size 16
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m md_rdm_amd.train --synthetic --gpus 8
 """
 import os
@@ -57,8 +60,8 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if args.precision != 32:
         raise SystemExit("only --precision 32 is built")
-    if not args.synthetic:
-        raise SystemExit("dataset loaders are out of scope of this round (SURVEY.md 8(f)); use --synthetic")
+    if not args.synthetic and not args.nyu_path:
+        raise SystemExit("give --nyu_path DIR (raw .h5 / .npz samples) or --synthetic")
     if args.seed is None:
         args.seed = random.randrange(4294967295)
     torch.manual_seed(args.seed)
@@ -83,14 +86,34 @@ def main(argv=None):
     logger = MetricLogger(args.metrics if "delta1" in args.metrics else ["delta1"] + list(args.metrics))
     H, W = args.size
     steps = 1 if args.dev else args.max_steps
-    for epoch in range(args.max_epochs):
-        model.train()
-        t0 = time.time()
+    train_loader = val_loader = None
+    if args.nyu_path:
+        from .dataloaders import NYUDataset, PrefetchLoader
+        train_loader = PrefetchLoader(NYUDataset(args.nyu_path, split="train", output_size=(H, W)), args.batch_size, seed=args.seed, device=dev,
+                                      rank=rank, world=world)
+        val_loader = PrefetchLoader(NYUDataset(args.nyu_path, split="val", output_size=(H, W)), 1, device=dev, drop_last=False, rank=rank, world=world)
+        steps = 1 if args.dev else len(train_loader)
+
+    def train_batches(epoch):
+        if train_loader is not None:
+            first = None
+            for it, (x, y) in enumerate(train_loader):
+                if it >= steps:
+                    break
+                first = first if first is not None else (x, y)
+                yield first if args.overfit else (x, y)
+            return
         for it in range(steps):
             seed = 1234 + rank if args.overfit else 1234 + rank + 1000 * (epoch * steps + it)
             x, y = filler.synthetic_batch(args.batch_size, H, W, seed=seed)
+            yield torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+    for epoch in range(args.max_epochs):
+        model.train()
+        t0 = time.time()
+        for it, (x, y) in enumerate(train_batches(epoch)):
             opt.zero_grad()
-            loss, parts = harness.training_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+            loss, parts = harness.training_step(model, x, y)
             loss.backward()
             opt.step(grad_scale=sync.finish())
             if rank == 0:
@@ -99,10 +122,18 @@ def main(argv=None):
         torch.cuda.synchronize()
         model.eval()
         with torch.no_grad():
-            x, y = filler.synthetic_batch(1, H, W, seed=99)
-            y_hat, y_n = harness.validation_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
-        val = logger.log_val(y_hat, y_n)           # the reference compares the (log-domain) recombination with the normalised target as is (module.py:117)
-        d1 = val["delta1"]
+            logger.reset()
+            if val_loader is not None:
+                for vi, (x, y) in enumerate(val_loader):
+                    y_hat, y_n = harness.validation_step(model, x, y)
+                    logger.log_val(y_hat, y_n)     # the reference compares the (log-domain) recombination with the normalised target as is (module.py:117)
+                    if args.dev:
+                        break
+            else:
+                x, y = filler.synthetic_batch(1, H, W, seed=99)
+                y_hat, y_n = harness.validation_step(model, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+                logger.log_val(y_hat, y_n)
+        d1 = logger.computer.avg("delta1")         # epoch mean of the per-step values, as Lightning's self.log aggregates val_delta1
         sched.step(d1)
         if rank == 0:
             print(f"epoch {epoch}: {steps * args.batch_size * world / (time.time() - t0):.1f} img/s, val_delta1 {d1:.4f}, lr {opt.lr:g}", flush=True)
