@@ -57,6 +57,7 @@ def main(argv=None):
     parser.add_argument("--nyu_path", type=str, default=None)
     parser.add_argument("--synthetic", action="store_true")
     parser.add_argument("--size", type=int, nargs=2, default=[226, 226], help="input HxW (module.py:19 feeds 226x226)")
+    parser.add_argument("--relative_decoders", type=int, nargs="*", default=[], help="subset of 6 7 8 9: the relative decoders the reference keeps commented out (RDM_Net.py:57-60)")
     args = parser.parse_args(argv)
     if args.precision != 32:
         raise SystemExit("only --precision 32 is built")
@@ -78,7 +79,7 @@ def main(argv=None):
     from . import filler, harness, parallel
     from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
-    model = DepthEstimationNet().to(dev)
+    model = DepthEstimationNet(relative_decoders=tuple(args.relative_decoders)).to(dev)
     model.flatten_parameters()
     sync = parallel.attach(model)
     opt = harness.FusedAdamW(model, lr=args.learning_rate)

@@ -428,6 +428,74 @@ def run_op_goldens(RDM, cp, u, l, out):
     print("op goldens:", len(g), "arrays")
 
 
+
+def run_rel_goldens(RDM, cp, out):
+    """the relative decoders d_6..d_9 as the reference's own classes build them (RDM_Net.py:57-60 are commented
+    out, but ``Decoder(in_channels=1056, num_wsm_layers=k, DORN=False, id=6+k, ...)`` is live code), at FULL width, fed a
+    deterministic encoder output, and the five-decoder tail of forward() (:106-133) composed from the reference's functions.
+    conv1's bias is set to +2 with small weights so the 1-channel map is positive (nothing in the reference constrains it;
+    ratios, logs and geometric means of a non-positive map are NaN)."""
+    g = {}
+    tt = torch.from_numpy
+    quant = RDM.Quantization()
+    B = 2
+    x = tt(filler.uniform("rel.x", (B, 1056, 8, 8), -1.0, 1.0))
+    rows = []
+    cnt = np.floor(filler.uniform("rel.cnt", (B, 1, 8, 8), 5, 80)).astype(np.int64)          # a DORN count map for d_1
+    x_d1 = tt(cnt)
+    f_d1 = cp.decompose_depth_map([], torch.div(x_d1, cp.quick_gm(x_d1.view(B, 64, 1), 8).expand(B, 64).view(B, 1, 8, 8)), 3)[::-1]
+    rows.append(f_d1)
+    for did in (6, 7, 8, 9):
+        torch.manual_seed(did)
+        dec = RDM.Decoder(in_channels=1056, num_wsm_layers=did - 6, DORN=False, id=did, quant=quant)
+        sd = dec.state_dict()
+        for key, t in sd.items():
+            if t.numel() and t.dtype.is_floating_point:
+                t.copy_(tt(filler.state_value(f"d_{did}." + key, tuple(t.shape))))
+        with torch.no_grad():
+            dec.conv1.weight.mul_(0.02)
+            dec.conv1.bias.fill_(2.0)
+        dec.train()
+        with torch.no_grad():
+            h = dec.dense_layer(x)
+            g[f"rel{did}_dense_stats"] = stats3(h)
+            g[f"rel{did}_dense_head"] = h[:, -48:, :2, :2].numpy()
+            h = dec.wsm_block(h)
+            g[f"rel{did}_wsm_stats"] = stats3(h)
+            feat = dec.conv1(h)
+            g[f"rel{did}_feat"] = feat.numpy()
+            outm = dec.ord_layer(feat.clone())
+        g[f"rel{did}_out"] = outm.numpy()
+        g[f"rel{did}_rm_norm2_24"] = dec.dense_layer.denselayer24.norm2.running_mean.numpy().copy()
+        g[f"rel{did}_rv_norm1_1"] = dec.dense_layer.denselayer1.norm1.running_var.numpy().copy()
+        g[f"rel{did}_keys"] = np.array([f"{k_} {tuple(v.shape)}" for k_, v in sd.items()])
+        n = int(np.log2(outm.shape[2]))
+        rows.append(cp.decompose_depth_map([], outm, n, relative_map=True)[::-1])
+        print(f"  d_{did}: feat {tuple(feat.shape)} out {tuple(outm.shape)} range [{float(outm.min()):.3f}, {float(outm.max()):.3f}]", flush=True)
+    g["rel_row_lens"] = np.array([len(r) for r in rows])
+    y_hat = cp.relative_fine_detail_matrix(rows, False)
+    g["rel_matrix_shapes"] = np.array([list(m.shape) for m in y_hat])
+    sizes = [m.shape[1] for m in y_hat] + [0] * (8 - len(y_hat))
+    g["rel_vector_sizes"] = np.array(sizes)
+    torch.manual_seed(0)
+    wl = RDM.Weights(vector_sizes=sizes, use_cuda=False, relative_only=False)
+    with torch.no_grad():
+        for i, w in enumerate(wl.weight_list):
+            if w.numel():
+                w.copy_(tt(filler.uniform(f"rel.w{i}", tuple(w.shape), 0.1, 0.6)))
+    pred = wl(y_hat)
+    for i, t in enumerate(pred):
+        g[f"rel_yhat{i}"] = t.detach().numpy()
+    (sum((t.double() ** 2).sum() for t in pred)).backward()
+    for i, w in enumerate(wl.weight_list):
+        if w.numel():
+            g[f"rel_dw{i}"] = w.grad.numpy()
+    comps = [t.detach() for t in pred]
+    g["rel_recombination"] = cp.recombination(comps, n=7).numpy()
+    np.savez_compressed(os.path.join(out, "rel_goldens.npz"), **g)
+    print("rel goldens:", len(g), "arrays")
+
+
 def main():
     install_torchvision_standin()
     cwd = prepare_cwd()
@@ -438,11 +506,13 @@ def main():
     import loss as l
     RDM.use_cuda = False            # global read at call time (RDM_Net.py:63,100)
     out = HERE
-    which = sys.argv[1:] or ["ops", "wsm", "net"]
+    which = sys.argv[1:] or ["ops", "wsm", "rel", "net"]
     if "ops" in which:
         run_op_goldens(RDM, cp, u, l, out)
     if "wsm" in which:
         run_wsm_goldens(RDM, out)
+    if "rel" in which:
+        run_rel_goldens(RDM, cp, out)
     if "net" in which:
         run_net_goldens(RDM, cp, u, l, out)
     shutil.rmtree(cwd, ignore_errors=True)

@@ -1,0 +1,131 @@
+"""the relative decoders d_6..d_9 wired into the live graph, against goldens produced by the reference's own
+``Decoder`` / ``Ordinal_Layer`` / ``Weights`` classes at full width (tests/golden/make_golden.py::run_rel_goldens)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from md_rdm_amd import filler
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rel_goldens.npz"))
+
+
+def stats3(t):
+    t = t.double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.abs().max().item()])
+
+
+def _decoder(did):
+    from md_rdm_amd.network import RDM_Net
+    dec = RDM_Net.Decoder(in_channels=1056, num_wsm_layers=did - 6, DORN=False, id=did, quant=RDM_Net.Quantization())
+    sd = dec.state_dict()
+    assert [f"{k} {tuple(v.shape)}" for k, v in sd.items()] == list(G[f"rel{did}_keys"])
+    for key, t in sd.items():
+        if t.numel() and t.dtype.is_floating_point:
+            t.copy_(torch.from_numpy(filler.state_value(f"d_{did}." + key, tuple(t.shape))))
+    with torch.no_grad():
+        dec.conv1.weight.mul_(0.02)
+        dec.conv1.bias.fill_(2.0)
+    return dec.cuda().train()
+
+
+@pytest.mark.parametrize("did", [6, 7, 8, 9])
+def test_relative_decoder_features_and_head(did):
+    from md_rdm_amd.network import RDM_Net
+    dec = _decoder(did)
+    x = torch.from_numpy(filler.uniform("rel.x", (2, 1056, 8, 8), -1.0, 1.0)).cuda()
+    blk = RDM_Net._dense_block_forward(dec.dense_layer, x, True)                       # (B,8,8,2208) NHWC
+    h = blk.permute(0, 3, 1, 2)
+    np.testing.assert_allclose(stats3(h), G[f"rel{did}_dense_stats"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(h[:, -48:, :2, :2].cpu().numpy(), G[f"rel{did}_dense_head"], rtol=2e-3, atol=2e-4)
+    # BatchNorm side effects of the training-mode forward (running statistics as nn.BatchNorm2d updates them)
+    np.testing.assert_allclose(dec.dense_layer.denselayer24.norm2.running_mean.cpu().numpy(), G[f"rel{did}_rm_norm2_24"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(dec.dense_layer.denselayer1.norm1.running_var.cpu().numpy(), G[f"rel{did}_rv_norm1_1"], rtol=1e-4, atol=1e-6)
+    assert int(dec.dense_layer.denselayer7.norm2.num_batches_tracked) == 1
+    dec2 = _decoder(did)                                                                # fresh running statistics
+    feat = dec2.features(x)
+    ref = G[f"rel{did}_feat"]
+    assert feat.shape == ref.shape
+    np.testing.assert_allclose(feat.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    # the head on the reference's own feature map: ratio grid -> Lloyd -> ALS (discrete steps: same input => same bins)
+    out = dec2.ord_layer(torch.from_numpy(ref).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), G[f"rel{did}_out"], rtol=3e-5, atol=3e-5)
+    # end to end the Lloyd bins may flip where a ratio sits within float rounding of a threshold: loose, but must stay close
+    e2e = dec2(x).cpu().numpy()
+    assert np.isfinite(e2e).all()
+    close = np.isclose(e2e, G[f"rel{did}_out"], rtol=2e-3, atol=2e-3).mean()
+    assert close > 0.97, close
+
+
+def test_five_decoder_tail_matches_reference():
+    """forward() lines 106-133 with decoders 1,6,7,8,9: decompose(relative_map=True), matrix form, Weights, recombination."""
+    from md_rdm_amd.network import RDM_Net, computations as cp
+    B = 2
+    cnt = torch.from_numpy(np.floor(filler.uniform("rel.cnt", (B, 1, 8, 8), 5, 80)).astype(np.int64)).cuda()
+    norm = cp.gm_normalize(cnt, 1.0 / 64).float()
+    rows = [cp.decompose_depth_map([], norm, 3)[::-1]]
+    for did in (6, 7, 8, 9):
+        rows.append(cp.decompose_depth_map([], torch.from_numpy(G[f"rel{did}_out"]).cuda(), did - 3, relative_map=True)[::-1])
+    assert [len(r) for r in rows] == list(G["rel_row_lens"])
+    A = cp.relative_fine_detail_matrix(rows, True)
+    assert [list(m.shape) for m in A] == G["rel_matrix_shapes"].tolist()
+    model = RDM_Net.DepthEstimationNet(relative_decoders=(6, 7, 8, 9))
+    wl = model.weight_layer.cuda()
+    assert [w.shape[0] for w in wl.weight_list] == list(G["rel_vector_sizes"])
+    with torch.no_grad():
+        for i, w in enumerate(wl.weight_list):
+            if w.numel():
+                w.copy_(torch.from_numpy(filler.uniform(f"rel.w{i}", tuple(w.shape), 0.1, 0.6)))
+    pred = wl(A)
+    for i, t in enumerate(pred):
+        np.testing.assert_allclose(t.detach().cpu().numpy(), G[f"rel_yhat{i}"], rtol=2e-5, atol=5e-6)
+    sum((t.double() ** 2).sum() for t in pred).backward()
+    for i, w in enumerate(wl.weight_list):
+        if w.numel():
+            np.testing.assert_allclose(w.grad.cpu().numpy(), G[f"rel_dw{i}"], rtol=2e-4, atol=1e-5)
+    rec = cp.recombination([t.detach() for t in pred], n=7)
+    np.testing.assert_allclose(rec.cpu().numpy(), G["rel_recombination"], rtol=1e-5, atol=1e-5)
+
+
+def test_model_with_relative_decoders_trains():
+    """Whole model with decoders 1,6,7,8,9: 7-level prediction, gradients reach the stack and the weight vectors but not
+    the relative decoders (Lloyd severs the graph in the reference as well), one optimiser step runs."""
+    from md_rdm_amd import harness
+    from md_rdm_amd.network import RDM_Net
+    torch.manual_seed(0)
+    model = RDM_Net.DepthEstimationNet(relative_decoders=(6, 7, 8, 9))
+    filler.fill_state_dict(model.state_dict())
+    with torch.no_grad():
+        for did in (6, 7, 8, 9):
+            d = getattr(model, f"d_{did}")
+            d.conv1.weight.mul_(0.02)
+            d.conv1.bias.fill_(2.0)
+    model = model.cuda().train()
+    model.flatten_parameters()
+    model.direct_grads = True
+    x, y = filler.synthetic_batch(2, 228, 228, seed=5)
+    x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    y_hat, x_d1, ord_labels = model(x)
+    assert [tuple(t.shape) for t in y_hat] == [(2, 1, 2 ** k, 2 ** k) for k in range(7)]
+    assert all(torch.isfinite(t).all() for t in y_hat)
+    opt = harness.FusedAdamW(model, lr=1e-4)
+    opt.zero_grad()
+    loss, parts = harness.training_step(model, x, y)
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert model.weight_layer.f4.grad is not None and torch.isfinite(model.weight_layer.f4.grad).all()
+    assert model.encoder.conv_e1.weight.grad is not None
+    assert model.d_9.conv1.weight.grad is None and model.d_7.wsm_block.WSM_1.conv2_2.weight.grad is None
+    before = model.weight_layer.f1.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.weight_layer.f1.detach())
+    with pytest.raises(Exception, match="square 8x8"):
+        model(torch.zeros(1, 3, 228, 304, device="cuda"))
+
+
+def test_rejects_unknown_decoder_ids():
+    from md_rdm_amd.network import RDM_Net
+    with pytest.raises(ValueError):
+        RDM_Net.DepthEstimationNet(relative_decoders=(5,))
