@@ -1159,7 +1159,10 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const long Mpix = (long)a.g.B * a.g.Ho * a.g.Wo;
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
-  const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
+  // a ragged last column tile of the 128 x 96 config wastes up to 25 % of the MFMAs (C = 144: 2 x 96); 256 x 48 tiles fit every
+  // C that is a multiple of 48 (PMC: the 1x1 wgrad ran its MFMA pipe at 78 % for 66 % useful - the gap was this waste)
+  const bool tall = !narrow && g_variant != 13 && a.C % 96 != 0 && (double)cdiv(a.C, 96) * 96 > 1.04 * a.C;
+  const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : tall ? (long)cdiv(a.C, 48) * cdiv(a.N, 256) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
   // 3x3 / stride 1 / pad 1 with few output channels: the row kernel (3 taps per block)
   const bool row3 = g_variant != 9 && kslabs >= 1024 && a.N <= 96 &&   // long K only: at M <= 4560 the generic kernel's finer tiles win (A/B)
                     a.G2 == nullptr && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
@@ -1178,6 +1181,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
     const long padded = (a.n_items + 7) / 8 * 8;
     hipLaunchKernelGGL(conv_wgrad3_row_kernel, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
   } else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
+  else if (tall) launch_wgrad_cfg<4, 3, 4, 1>(a, taps, s);  // 256 x 48: input-channel counts are multiples of 48, not of 96
   else launch_wgrad_cfg<4, 3, 2, 2>(a, taps, s);          // 128 x 96
   RDM_LAUNCH_OK();
   return 0;

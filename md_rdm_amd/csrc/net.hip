@@ -116,7 +116,12 @@ struct NetImpl {
   bool dz_busy[2] = {false, false};
   int ensure_side() {
     if (side) return 0;
-    RDM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    // lowest priority: the side stream carries bulk work (weight gradients) that should fill what the dependent chain on the
+    // caller's stream leaves free, not compete with it for workgroup slots
+    int prio_least = 0, prio_greatest = 0;
+    RDM_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (g_variant == 14) RDM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    else RDM_HIP_OK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dy, hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[0], hipEventDisableTiming));
