@@ -12,6 +12,7 @@ int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
                         int training, hipStream_t s);
+int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t s);
 int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A, const float* Bc, const float* Cc,
                    int M, int C, bool accumulate, hipStream_t s);
 int launch_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H, int W, int C, hipStream_t s);

@@ -187,6 +187,35 @@ int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x
   return 0;
 }
 
+// Zero fill as an ordinary kernel.  hipMemsetAsync / hipMemset2DAsync go through the runtime's fill path, which
+// showed up as ~0.8 ms of GPU idle time per step in front of 360 fills (kernel trace); a plain launch queues back-to-back.
+// rows x row_floats floats with a row pitch of `ld` floats (ld == row_floats: contiguous).  All multiples of 4, 16-B aligned.
+__global__ __launch_bounds__(256) void k_zero_rows(float* __restrict__ p, long ld4, long row4, long total4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long r = i / row4, c = i - r * row4;
+    st4(p + (r * ld4 + c) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+__global__ __launch_bounds__(256) void k_zero_bytes(unsigned char* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+
+int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t s) {
+  if (rows <= 0 || row_floats <= 0) return 0;
+  if ((row_floats & 3) || (ld & 3) || ((uintptr_t)p & 15)) {           // odd shapes: byte loop (never on the hot path)
+    RDM_CHECK_ARG(ld == row_floats, "zero fill: a strided region needs 16-byte aligned rows");
+    const size_t n = (size_t)rows * row_floats * 4;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)std::min<size_t>(cdiv(n, 256), 4096)), dim3(256), 0, s, reinterpret_cast<unsigned char*>(p), n);
+  } else {
+    long row4 = row_floats / 4, ld4 = ld / 4;
+    if (ld == row_floats) { row4 *= rows; ld4 = row4; rows = 1; }     // contiguous: one long row
+    const long total4 = rows * row4;
+    hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)std::min<long>(cdiv(total4, 256), 256 * 16)), dim3(256), 0, s, p, ld4, row4, total4);
+  }
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
 // BN backward in ONE pass: the coefficient computation of k_bn_bwd_coeffs is done per thread for its
 // four channels (a thread keeps its channel group and walks rows), then dst (=|+=) A*dz + B*x + Cc.
 // Removes a 4-us dependent launch from every BatchNorm of the backward chain (156 per step) - and with

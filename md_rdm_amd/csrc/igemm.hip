@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "rdm_common.h"
+#include "elementwise.h"
 
 namespace rdm {
 
@@ -1059,7 +1060,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     epi = EPI_ATOMIC;
   } else if (split > 1) {   // split-K: f32 atomics into a zeroed (possibly strided) output slice
     epi = epi == EPI_MASK_STATS ? EPI_MASK_STATS_ATOMIC : EPI_ATOMIC;
-    RDM_HIP_OK(hipMemset2DAsync(a.out, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, (size_t)a.M, s));
+    if (int zrc = launch_zero_rows(a.out, a.M, a.N, a.ldc, s)) return zrc;
   }
   a.split_k = split;
   a.xcd_flat = g_variant == 11 || a.N <= 48;      // a single column tile has nothing to share (and the 3x3 forward measured 4 % slower remapped)

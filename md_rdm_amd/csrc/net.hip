@@ -279,7 +279,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     // ---- side stream: part A of layer i+1 (channels [0, cin), final once layer i-1 has published its statistics) ----
     if (pipelined && i + 1 < layers) {
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_fs[(i + 1) & 1], 0));                 // recorded at the end of layer i-1
-      RDM_HIP_OK(hipMemsetAsync(at<float>(ws, n.lws[b][i + 1].Y), 0, (size_t)g.M * g.cb * sizeof(float), side));
+      if ((rc = launch_zero_rows(at<float>(ws, n.lws[b][i + 1].Y), 1, (long)g.M * g.cb, (long)g.M * g.cb, side))) return rc;
       if ((rc = finalize_norm1(n, b, i + 1, 0, cin, true, ws, T, training, side))) return rc;
       if ((rc = conv1_range(n, b, i + 1, 0, cin, true, false, ws, T, side))) return rc;
       RDM_HIP_OK(hipEventRecord(n.ev_fa[(i + 1) & 1], side));
@@ -344,7 +344,7 @@ int forward_transition(NetImpl& n, int t, void* ws, void* const* T, int training
 }
 
 int zero_f32(float* p, size_t n, hipStream_t s) {
-  RDM_HIP_OK(hipMemsetAsync(p, 0, n * sizeof(float), s));
+  if (int rc = launch_zero_rows(p, 1, (long)n, (long)n, s)) return rc;
   return 0;
 }
 
