@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
 // fewer global loads, BN-ReLU VALU ops and LDS stores per MFMA.  Weights are staged per tap
 // (double-buffered, one barrier per tap).  Needs 2*(W+1) <= 256 (else the launcher uses the generic path).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int HL, bool DGRAD>           // HL = float4 halo loads per thread per channel slab = ceil(halo / 64)
+template <int EPI, int HL, bool DGRAD, int MT>   // HL = float4 halo loads per thread per channel slab = ceil(halo / 64); MT = 16-row tiles per wave
 __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
   // DGRAD: the same machinery run on the output gradient: dx[m][c] = sum_{tap,n} dy[m + (1-r)*W + (1-q)][n] * w[tap][n][c]
   // (taps mirrored, weights read along their input-channel rows), epilogue = ReLU gate + BN-backward sums.
-  constexpr int MT = 4, NT = 3, BM = 256, BN = 48;
+  constexpr int NT = 3, BM = MT * 64, BN = 48;     // MT = 4: 256 pixels per block; MT = 2: 128 (layers with few pixels)
   // LDS image [k][pixel]: row stride = 16 mod 32 floats, so the two k-groups of a 32-lane half read disjoint
   // bank halves; k-quad kq is skewed by 8*kq floats, so the transposing ds_write_b32 of a half-wave
   // (8 pixels x 4 k-quads) lands on 32 distinct banks too.  (Was stride = 4 mod 32: 2-way conflicts both ways.)
@@ -1028,7 +1028,8 @@ template <bool TAPS, bool BK_, int EPI>
 static void launch_fwd_epi(const FwdArgs& a, int cfg, int split, hipStream_t s) {
   if (cfg == 0) launch_fwd_cfg<4, 3, 4, 1, TAPS, BK_, EPI>(a, split, s);        // 256 x 48
   else if (cfg == 1) launch_fwd_cfg<4, 3, 2, 2, TAPS, BK_, EPI>(a, split, s);   // 128 x 96
-  else launch_fwd_cfg<2, 3, 2, 2, TAPS, BK_, EPI>(a, split, s);                 //  64 x 96
+  else if (cfg == 2) launch_fwd_cfg<2, 3, 2, 2, TAPS, BK_, EPI>(a, split, s);   //  64 x 96
+  else launch_fwd_cfg<2, 3, 4, 1, TAPS, BK_, EPI>(a, split, s);                 // 128 x 48
 }
 
 int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s) {
@@ -1050,8 +1051,12 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   if (a.N % 96 == 0 && (t1 >= 512 || a.M <= 128)) cfg = 1;
   if (t1 >= 512 && (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N) cfg = 1;      // a ragged last N tile is fine up to 4 % waste (A/B: 110.7 vs 107.6 TF)
   if (a.M <= 64) cfg = 2;
+  // few rows (dense_e4: 4560, decoder: 1280): 128 x 48 tiles give 4x the workgroups of 256 x 48 before any split-K and no ragged
+  // column tile; measured 20-45 % faster than 256 x 48 + deeper split-K on the 1x1 convs of those blocks (64 x 96 ties)
+  if (!taps && a.M <= 32768 && a.M > 64 && g_variant != 16) cfg = 3;
+  if (!taps && cfg == 0 && g_variant != 20) cfg = 3;       // also at dense_e2 size: 1x1 dgrad 121.1 vs 116.3 TFLOP/s
   // (a 64x96 wave tile - 256x96 block, 2 waves/SIMD - was measured: +1 % on the 1x1 forward, -21 % on the 3x3 dgrad)
-  const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : (long)cdiv(a.M, 64) * cdiv(a.N, 96);
+  const long tiles = cfg == 0 ? t0 : cfg == 1 ? t1 : cfg == 2 ? (long)cdiv(a.M, 64) * cdiv(a.N, 96) : (long)cdiv(a.M, 128) * cdiv(a.N, 48);
   int split = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs, 256 * 4);
   if (epi == EPI_STORE_STATS) split = 1;                 // sum of squares is not linear in the K-partials
   if (epi == EPI_STORE && a.bias != nullptr) split = 1;
@@ -1081,15 +1086,30 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     prof.kind = halo_dgrad ? 3 : 2;
     // LDS halo kernel; K is split over whole channel slabs (a split keeps its 9-tap groups together).
     // `epi` / `split` were already resolved above (split > 1 => atomic epilogue, output zeroed).
+    // few pixels (dense_e4, decoder): 128-pixel tiles double the workgroups before any split
+    const bool small = a.M <= 8192 && 128 + 2 * (a.g.W + 1) <= 256 && g_variant != 21;
+    const int bm = small ? 128 : 256;
     int sp = split;
+    if (small && epi != EPI_STORE_STATS && !(epi == EPI_STORE && a.bias != nullptr) && !a.accumulate) {
+      sp = a.split_k > 0 ? a.split_k : pick_split_k((long)cdiv(a.N, 48) * cdiv(a.M, bm), kslabs, 256 * 4);
+      if (sp > 1 && split == 1) {                           // the generic path above decided against a split: zero the output now
+        epi = epi == EPI_MASK_STATS ? EPI_MASK_STATS_ATOMIC : EPI_ATOMIC;
+        if (int zrc = launch_zero_rows(a.out, a.M, a.N, a.ldc, s)) return zrc;
+      } else if (sp == 1 && split > 1) {
+        sp = split;                                          // output already zeroed and epilogue already atomic: keep a split
+      }
+    }
     if (sp > a.C / 16) sp = a.C / 16;
-    dim3 grid(cdiv(a.N, 48), cdiv(a.M, 256), sp);
-    const int hl = cdiv(256 + 2 * (a.g.W + 1), 64);          // 5 (W <= 31), 6 (<= 63), 7 (<= 95), 8 (<= 127)
+    dim3 grid(cdiv(a.N, 48), cdiv(a.M, bm), sp);
+    const int hl = cdiv(bm + 2 * (a.g.W + 1), 64);           // 256-pixel tiles: 5 (W <= 31) .. 8 (<= 127); 128-pixel tiles: 3, 4
 #define RDM_HALO2(E_, D_)                                                                                       \
-    if (hl <= 5) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 5, D_>), grid, dim3(256), 0, s, a);                \
-    else if (hl == 6) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 6, D_>), grid, dim3(256), 0, s, a);           \
-    else if (hl == 7) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 7, D_>), grid, dim3(256), 0, s, a);           \
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 8, D_>), grid, dim3(256), 0, s, a);
+    if (small) {                                                                                                 \
+      if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 3, D_, 2>), grid, dim3(256), 0, s, a);           \
+      else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 4, D_, 2>), grid, dim3(256), 0, s, a);                   \
+    } else if (hl <= 5) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 5, D_, 4>), grid, dim3(256), 0, s, a);      \
+    else if (hl == 6) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 6, D_, 4>), grid, dim3(256), 0, s, a);        \
+    else if (hl == 7) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 7, D_, 4>), grid, dim3(256), 0, s, a);        \
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 8, D_, 4>), grid, dim3(256), 0, s, a);
 #define RDM_HALO(E_) if (halo_dgrad) { RDM_HALO2(E_, true) } else { RDM_HALO2(E_, false) }
     switch (epi) {
       case EPI_STORE: RDM_HALO(EPI_STORE) break;

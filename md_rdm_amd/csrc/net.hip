@@ -222,7 +222,10 @@ ConvGeom geom3x3(int B, int H, int W, int dir) { return ConvGeom{B, H, W, H, W, 
 
 // statistics of rows of a matrix are fused in the conv epilogue on big layers; split-K layers
 // (few rows) reduce with a separate pass
-inline bool fuse_stats(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536; }   // flat between 512 and 3072 (swept)
+inline bool fuse_stats(int M, int N) {
+  if (g_variant == 18 && M <= 8192) return (long)cdiv(M, 128) * cdiv(N, 48) >= 256;      // experiment: small-M layers unsplit with fused statistics
+  return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536;   // flat between 512 and 3072 (swept)
+}
 
 // norm1 finalisation of layer i restricted to channels [c_lo, c_hi) of the block buffer
 int finalize_norm1(NetImpl& n, int b, int i, int c_lo, int c_hi, bool count_batch, void* ws, void* const* T, int training, hipStream_t s) {
