@@ -1183,7 +1183,10 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   // a ragged last column tile of the 128 x 96 config wastes up to 25 % of the MFMAs (C = 144: 2 x 96); 256 x 48 tiles fit every
   // C that is a multiple of 48 (PMC: the 1x1 wgrad ran its MFMA pipe at 78 % for 66 % useful - the gap was this waste)
   const bool tall = !narrow && g_variant != 13 && a.C % 96 != 0 && (double)cdiv(a.C, 96) * 96 > 1.04 * a.C;
-  const long tiles = narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : tall ? (long)cdiv(a.C, 48) * cdiv(a.N, 256) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
+  // few pixels to contract over (dense_e4, decoder): half-size tiles (1x1: 93 vs 116 us at M = 4560, C = 1224; 3x3: 47 vs 55 us)
+  const bool few = Mpix <= 8192 && g_variant != 23;
+  const long tiles = few ? (narrow ? (long)cdiv(a.C, 128) * cdiv(a.N, 48) : (long)cdiv(a.C, 48) * cdiv(a.N, 128)) * ntaps :
+                     narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : tall ? (long)cdiv(a.C, 48) * cdiv(a.N, 256) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
   // 3x3 / stride 1 / pad 1 with few output channels: the row kernel (3 taps per block)
   const bool row3 = g_variant != 9 && kslabs >= 1024 && a.N <= 96 &&   // long K only: at M <= 4560 the generic kernel's finer tiles win (A/B)
                     a.G2 == nullptr && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
@@ -1201,7 +1204,9 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
     a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
     const long padded = (a.n_items + 7) / 8 * 8;
     hipLaunchKernelGGL(conv_wgrad3_row_kernel, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
-  } else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
+  } else if (few && !narrow) launch_wgrad_cfg<2, 3, 4, 1>(a, taps, s);   // 128 x 48
+  else if (few) launch_wgrad_cfg<3, 2, 1, 4>(a, taps, s);                //  48 x 128
+  else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
   else if (tall) launch_wgrad_cfg<4, 3, 4, 1>(a, taps, s);  // 256 x 48: input-channel counts are multiples of 48, not of 96
   else launch_wgrad_cfg<4, 3, 2, 2>(a, taps, s);          // 128 x 96
   RDM_LAUNCH_OK();
