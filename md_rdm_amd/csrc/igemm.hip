@@ -732,9 +732,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
 // into the A fragments - so the activation ring can hold whatever linear neighbour is in memory.
 // LDS strides are 16 mod 32 floats: the four k-groups of a fragment read hit disjoint bank halves
 // (SQ_LDS_BANK_CONFLICT = 0; the generic kernel spends 38 % of its LDS cycles in conflicts).
-// 144 accumulator VGPRs per wave -> 2 waves/SIMD; the fragment fetch is software-pipelined by hand.
-// Measured on the dense_e2 conv2 (M 69312, C 2736, N 48): 1.57 ms / 104.7 TFLOP/s vs 1.74 ms / 94.1.
+// 144 accumulator VGPRs per wave -> 2 waves/SIMD at 219 VGPRs (BN scale/shift kept in LDS to stay under 224: two such waves
+// leave one 64-VGPR wave slot per SIMD to the kernels of the dependent chain).  PIPE = fragment fetch software-pipelined by
+// hand (251 VGPRs).  Measured on the dense_e2 conv2 (M 69312, C 2736, N 48): 1.61 ms (PIPE 1.52) vs 1.74 ms generic.
 // ---------------------------------------------------------------------------------------------
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
   constexpr int WAVES = 4;
   constexpr int MT = 3, NT = 16 / WAVES;              // wave tile 48 (n) x 64 (c), times 3 taps
@@ -773,8 +775,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
   const bool xcol_ok = c0 + xr4 * 4 < p.C;
   const unsigned xcol = (unsigned)((c0 + xr4 * 4) * 4);
   const bool bnrelu = p.x_scale != nullptr;
-  float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bnrelu && xcol_ok) { bsc = ld4(p.x_scale + c0 + xr4 * 4); bsh = ld4(p.x_shift + c0 + xr4 * 4); }
+  // the thread's BN scale / shift live in LDS, not in 8 VGPRs: 144 accumulators + fragments already fill the register budget
+  __shared__ __attribute__((aligned(16))) float Ssc[BN], Ssh[BN];
+  if (tid < BN / 4) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bnrelu && c0 + tid * 4 < p.C) { sc = ld4(p.x_scale + c0 + tid * 4); sh = ld4(p.x_shift + c0 + tid * 4); }
+    *reinterpret_cast<float4*>(&Ssc[tid * 4]) = sc;
+    *reinterpret_cast<float4*>(&Ssh[tid * 4]) = sh;
+  }
+  __syncthreads();
   int xpix = s_begin * BK + dy * G.W - 1 + xk;          // linear input pixel of this thread's first row of chunk 0
   float4 rx[XL];
   auto load_chunk = [&]() {
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       float4 v = rx[i];
-      if (bnrelu) v = bnrelu4(v, bsc, bsh);
+      if (bnrelu) v = bnrelu4(v, *reinterpret_cast<const float4*>(&Ssc[xr4 * 4]), *reinterpret_cast<const float4*>(&Ssh[xr4 * 4]));
       *reinterpret_cast<float4*>(&Xr[(slot * 16 + xk + WAVES * i) * LDB + xr4 * 4]) = v;
     }
   };
@@ -862,18 +871,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
         for (int j = 0; j < NT; ++j) b[q][j] = Xr[row * LDB + wcol + j * 16 + l16];
       }
     };
-    fetch(0, fa[0], fb[0]);
+    if (PIPE) {
+      fetch(0, fa[0], fb[0]);
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      if (ks + 1 < BK / 4) fetch(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        if (ks + 1 < BK / 4) fetch(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][q][i], fb[ks & 1][q][j], acc[q][i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][q][i], fb[ks & 1][q][j], acc[q][i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {                                  // 224 VGPRs: leaves one 64-VGPR wave slot per SIMD to the dependent chain's kernels
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        fetch(ks, fa[0], fb[0]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q][i], fb[0][q][j], acc[q][i][j], 0, 0, 0);
+      }
     }
     if (more) { store_chunk(slot == 0 ? 2 : slot - 1); store_g(buf ^ 1); }   // chunk t+2 -> slot (t+2) mod 3
     __syncthreads();
@@ -1203,7 +1225,10 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   if (row3) {
     a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
     const long padded = (a.n_items + 7) / 8 * 8;
-    hipLaunchKernelGGL(conv_wgrad3_row_kernel, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
+    // shipped: the 219-VGPR build.  The hand-pipelined one (251 VGPRs) is 6 % faster alone (1.52 vs 1.61 ms) but fills the register
+    // file, so nothing of the dependent chain can run beside it: 199.7 vs 204.7 images/s over the whole step (in-process A/B)
+    if (g_variant == 26) hipLaunchKernelGGL(conv_wgrad3_row_kernel<true>, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad3_row_kernel<false>, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
   } else if (few && !narrow) launch_wgrad_cfg<2, 3, 4, 1>(a, taps, s);   // 128 x 48
   else if (few) launch_wgrad_cfg<3, 2, 1, 4>(a, taps, s);                //  48 x 128
   else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
