@@ -51,7 +51,10 @@ int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_fl
 /* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..6 (returns RDM_ERR_ARG beyond), *name = static
  * string naming the kernel, summed duration (ms), executed FLOPs and launch count of that kernel. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
-/* development switch between kernel variants for in-process A/B timing (0 = shipped) */
+/* development switch for in-process A/B timing of the measured alternatives DESIGN.md 4.1 cites (0 = shipped):
+ * 7 generic instead of halo 3x3, 8 no forward pipelining, 9 generic instead of row wgrad, 11 hardware block order,
+ * 13 128x96 wgrad tiles only, 14 default-priority side stream, 16/20 256x48 tiles on 1x1 convs, 21 256-pixel halo tiles only,
+ * 23 full-size wgrad tiles at small M, 26 hand-pipelined (251-VGPR) row wgrad.  Results never depend on it beyond float rounding. */
 void rdm_debug_variant(int32_t v);
 
 /* Attainable-peak microbenchmarks: float4 stream copy (HBM) and a register-only

@@ -13,8 +13,6 @@ int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const flo
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
                         int training, hipStream_t s);
 int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t s);
-int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A, const float* Bc, const float* Cc,
-                   int M, int C, bool accumulate, hipStream_t s);
 int launch_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H, int W, int C, hipStream_t s);
 int launch_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const float* sc, const float* sh, int B, int H, int W, int C,
                                  double* s0, double* s1, hipStream_t s);

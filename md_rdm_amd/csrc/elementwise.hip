@@ -157,36 +157,6 @@ int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const
   return 0;
 }
 
-// dst (=|+=) A[c]*dz + B[c]*x + Cc[c]
-template <bool ACC>
-__global__ __launch_bounds__(256) void k_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A,
-                                                 const float* Bc, const float* Cc, long total4, int C4) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    const long m = i / C4;
-    const int c = (int)(i - m * C4) * 4;
-    const float4 a = ld4(A + c), b = ld4(Bc + c), cc = ld4(Cc + c);
-    const float4 z = ld4(dz + m * ldz + c), xv = ld4(x + m * ldx + c);
-    float4 r;
-    r.x = fmaf(a.x, z.x, fmaf(b.x, xv.x, cc.x));
-    r.y = fmaf(a.y, z.y, fmaf(b.y, xv.y, cc.y));
-    r.z = fmaf(a.z, z.z, fmaf(b.z, xv.z, cc.z));
-    r.w = fmaf(a.w, z.w, fmaf(b.w, xv.w, cc.w));
-    float* d = dst + m * ldd + c;
-    if (ACC) { const float4 o = ld4(d); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-    st4(d, r);
-  }
-}
-
-int launch_affine3(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const float* A, const float* Bc,
-                   const float* Cc, int M, int C, bool accumulate, hipStream_t s) {
-  const long total4 = (long)M * (C / 4);
-  const int grid = (int)std::min<long>(cdiv(total4, 256), 256 * 16);
-  if (accumulate) hipLaunchKernelGGL(k_affine3<true>, dim3(grid), dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, A, Bc, Cc, total4, C / 4);
-  else hipLaunchKernelGGL(k_affine3<false>, dim3(grid), dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, A, Bc, Cc, total4, C / 4);
-  RDM_LAUNCH_OK();
-  return 0;
-}
-
 // Zero fill as an ordinary kernel.  hipMemsetAsync / hipMemset2DAsync go through the runtime's fill path, which
 // showed up as ~0.8 ms of GPU idle time per step in front of 360 fills (kernel trace); a plain launch queues back-to-back.
 // rows x row_floats floats with a row pitch of `ld` floats (ld == row_floats: contiguous).  All multiples of 4, 16-B aligned.

@@ -64,56 +64,6 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
       for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
 }
 
-// K-contiguous operands (NHWC activations, forward weights) are staged as a [row][16] image with an
-// XOR swizzle of the four 16-byte k-chunks: chunk' = chunk ^ ((-(row >> 2)) & 3).  With it every
-// ds_read_b128 lane group of a fragment read (lane -> row l&15, chunk l>>4) and every ds_write_b128
-// of the staging pass touches 16 distinct 4-bank slots: conflict-free with NO padding (16 KB per
-// 256-row buffer) and 4x fewer LDS instructions than a transposing [k][row] image.
-// Lane group g then owns k = 4g..4g+3 of the slab; MFMA step j contracts k = 4g + j on BOTH operands
-// (the contraction order inside a slab is free as long as A and B agree).
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
-
-template <int MT, int NT, bool B_KSTRIDED>
-__device__ __forceinline__ void mma_slab_sw(const float* __restrict__ As, const float* __restrict__ Bs, int ldb, int wrow, int wcol,
-                                            int l16, int g, f32x4 (&acc)[MT][NT]) {
-  float4 a[MT];
-  const int ch = (g ^ swz(l16)) * 4;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wrow + i * 16 + l16) * BK + ch]);
-  // k-step outer, accumulator tiles inner: consecutive MFMAs hit different accumulators (a dependent
-  // v_mfma_f32_16x16x4_f32 would wait 40 cycles instead of issuing every 32)
-  if (!B_KSTRIDED) {
-    float4 b[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wcol + j * 16 + l16) * BK + ch]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float av = q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w;
-          const float bv = q == 0 ? b[j].x : q == 1 ? b[j].y : q == 2 ? b[j].z : b[j].w;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
-        }
-  } else {
-    float b[4][NT];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[q][j] = Bs[(4 * g + q) * ldb + wcol + j * 16 + l16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float av = q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][j], acc[i][j], 0, 0, 0);
-        }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Global operands are read through buffer descriptors (SRD): 32-bit byte offsets instead of 64-bit
 // pointer arithmetic, and the hardware range check returns 0 for an out-of-range offset - so zero
@@ -208,14 +158,14 @@ __device__ __forceinline__ void conv_epilogue(const FwdArgs& p, f32x4 (&acc)[MT]
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI, bool SWZ, bool AFFINE = false>
+template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI>
 __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
-  constexpr int LDA = BM + 4, LDB = BN + 4;                        // [k][row] images (SWZ=false; dgrad weights always)
+  constexpr int LDA = BM + 4, LDB = BN + 4;                        // [k][row] images
   constexpr int AL = (BM * 4 + 255) / 256;                         // float4 loads of A per thread per slab
   constexpr int BL = B_KSTRIDED ? (BK * (BN / 4) + 255) / 256 : (BN * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float As[2][SWZ ? BM * BK : BK * LDA];    // SWZ: [row][16], XOR-swizzled k-chunks
-  __shared__ __attribute__((aligned(16))) float Bs[2][(B_KSTRIDED || !SWZ) ? BK * LDB : BN * BK];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
@@ -234,7 +184,6 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
     if (s_begin >= s_end) return;
   }
   const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A, p.a_bytes), srdW = make_srd(p.Wt, p.w_bytes);
-  const __amdgpu_buffer_rsrc_t srdA2 = make_srd(AFFINE ? p.A2 : p.A, p.a_bytes);
 
   // ---- per-thread operand bookkeeping, fixed for the whole K loop ----
   const int kq_a = tid & 3;                    // every A load of this thread covers the same k-quad
@@ -288,7 +237,6 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   // Raw loads only: nothing below consumes a loaded value, so the loads stay in flight across the
   // MFMA phase of the current slab; BN-ReLU / zero padding are applied when staging into LDS.
   float4 ra[AL], rb[BL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra2[AFFINE ? AL : 1], rfa = rsc, rfb = rsh, rfc = rsh;
   bool rok[AL];
   auto load_slab = [&]() {
     const int c0 = cur_cs * BK;
@@ -305,10 +253,8 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       }
       rok[i] = ok;
       ra[i] = bld4(srdA, ok ? a_voff[i] + a_uni : OOB);
-      if (AFFINE) ra2[i] = bld4(srdA2, ok ? a_voff[i] + a_uni : OOB);
     }
     if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
-    if (AFFINE) { rfa = ld4(p.aff_a + c0 + kq_a * 4); rfb = ld4(p.aff_b + c0 + kq_a * 4); rfc = ld4(p.aff_c + c0 + kq_a * 4); }
 #pragma unroll
     for (int i = 0; i < BL; ++i) rb[i] = bld4(srdW, b_voff[i] == OOB ? OOB : b_voff[i] + b_uni);
   };
@@ -320,18 +266,8 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
         const int row = idx >> 2;
         float4 v = ra[i];
         if (bnrelu) { v = bnrelu4(v, rsc, rsh); if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f); }
-        if (AFFINE) {
-          const float4 x = ra2[i];
-          v.x = fmaf(rfa.x, v.x, fmaf(rfb.x, x.x, rfc.x)); v.y = fmaf(rfa.y, v.y, fmaf(rfb.y, x.y, rfc.y));
-          v.z = fmaf(rfa.z, v.z, fmaf(rfb.z, x.z, rfc.z)); v.w = fmaf(rfa.w, v.w, fmaf(rfb.w, x.w, rfc.w));
-          if (!rok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (SWZ) {
-          *reinterpret_cast<float4*>(&As[buf][row * BK + ((kq_a ^ swz(row)) * 4)]) = v;
-        } else {
-          float* d = &As[buf][(kq_a * 4) * LDA + row];
-          d[0] = v.x; d[LDA] = v.y; d[2 * LDA] = v.z; d[3 * LDA] = v.w;
-        }
+        float* d = &As[buf][(kq_a * 4) * LDA + row];
+        d[0] = v.x; d[LDA] = v.y; d[2 * LDA] = v.z; d[3 * LDA] = v.w;
       }
     }
 #pragma unroll
@@ -340,12 +276,8 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       if (!B_KSTRIDED) {
         if (idx < BN * 4) {
           const int row = idx >> 2, kq = idx & 3;
-          if (SWZ) {
-            *reinterpret_cast<float4*>(&Bs[buf][row * BK + ((kq ^ swz(row)) * 4)]) = rb[i];
-          } else {
-            float* d = &Bs[buf][(kq * 4) * LDB + row];
-            d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
-          }
+          float* d = &Bs[buf][(kq * 4) * LDB + row];
+          d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
         }
       } else {
         if (idx < BK * (BN / 4)) {
@@ -371,8 +303,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   for (int s = s_begin; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
     if (more) { advance(); load_slab(); }
-    if (SWZ) mma_slab_sw<MT, NT, B_KSTRIDED>(As[buf], Bs[buf], LDB, wrow, wcol, l16, g, acc);
-    else mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
+    mma_slab<MT, NT>(As[buf], Bs[buf], LDA, LDB, wrow, wcol, l16, g, acc);
     if (more) store_slab(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -549,7 +480,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
 // wgrad kernel: both operands are read along their row (channel) dimension at a fixed pixel
 // (K = output pixels).  dW[tap][n][c] += sum_m G[m][n] * f(X[pix(m,tap)][c]).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS, bool AFFINE = false>
+template <int MT, int NT, int WM, int WN, bool TAPS>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -590,20 +521,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
   const int s_begin = split * per, s_end = min(nslab_total, s_begin + per);
   if (s_begin >= s_end) return;
   const __amdgpu_buffer_rsrc_t srdG = make_srd(p.G, p.g_bytes), srdX = make_srd(p.Xs, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t srdG2 = make_srd(AFFINE ? p.G2 : p.G, p.g_bytes);
 
   // fixed per thread: k (pixel within the slab) and the float4 column group of each load
   unsigned a_voff[AL];  int a_m[AL];
-  float4 fa[AFFINE ? AL : 1], fb[AFFINE ? AL : 1], fc[AFFINE ? AL : 1], ra2[AFFINE ? AL : 1];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int idx = tid + i * 256;
     const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
     const bool ok = idx < BK * (BM / 4) && n0 + r4 * 4 < p.N;
-    if (AFFINE) {
-      fa[i] = fb[i] = fc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) { fa[i] = ld4(p.aff_a + n0 + r4 * 4); fb[i] = ld4(p.aff_b + n0 + r4 * 4); fc[i] = ld4(p.aff_c + n0 + r4 * 4); }
-    }
     a_m[i] = ok ? s_begin * BK + k : 0x40000000;             // "never < Mpix" for dead lanes
     a_voff[i] = (unsigned)(s_begin * BK + k) * (unsigned)(p.ldg * 4) + (unsigned)((n0 + r4 * 4) * 4);
   }
@@ -637,7 +562,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < AL; ++i) {
       const bool okm = a_m[i] < Mpix;
       ra[i] = bld4(srdG, okm ? a_voff[i] : OOB);
-      if (AFFINE) { ra2[i] = bld4(srdG2, okm ? a_voff[i] : OOB); if (!okm) ra2[i].x = __int_as_float(0x7fc00000); }   // NaN tag = "row beyond M"
       a_m[i] += BK; a_voff[i] += (unsigned)(BK * p.ldg * 4);
     }
 #pragma unroll
@@ -663,17 +587,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
       const int idx = tid + i * 256;
       if (idx < BK * (BM / 4)) {
         const int k = idx / (BM / 4), r4 = idx - k * (BM / 4);
-        float4 v = ra[i];
-        if (AFFINE) {
-          const float4 x = ra2[i];
-          if (x.x != x.x) {                       // pixel beyond M: contributes nothing
-            v = make_float4(0.f, 0.f, 0.f, 0.f);
-          } else {
-            v.x = fmaf(fa[i].x, v.x, fmaf(fb[i].x, x.x, fc[i].x)); v.y = fmaf(fa[i].y, v.y, fmaf(fb[i].y, x.y, fc[i].y));
-            v.z = fmaf(fa[i].z, v.z, fmaf(fb[i].z, x.z, fc[i].z)); v.w = fmaf(fa[i].w, v.w, fmaf(fb[i].w, x.w, fc[i].w));
-          }
-        }
-        *reinterpret_cast<float4*>(&As[buf][k * LDA + r4 * 4]) = v;
+        *reinterpret_cast<float4*>(&As[buf][k * LDA + r4 * 4]) = ra[i];
       }
     }
 #pragma unroll
@@ -1037,13 +951,7 @@ template <int MT, int NT, int WM, int WN, bool TAPS, bool BK_, int EPI>
 static void launch_fwd_cfg(const FwdArgs& a, int split, hipStream_t s) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), split);
-  // shipped: [k][row] LDS image (in-process A/B on MI355X: 104 vs 88 TFLOP/s on the e2 3x3 forward, equal elsewhere);
-  // variant 1: XOR-swizzled [row][16] image with b128 accesses
-  if constexpr (!TAPS && BK_) {
-    if (a.A2 != nullptr) { hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, false, true>), grid, dim3(256), 0, s, a); return; }
-  }
-  if (g_variant == 1) hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI, false>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WM, WN, TAPS, BK_, EPI>), grid, dim3(256), 0, s, a);
 }
 
 template <bool TAPS, bool BK_, int EPI>
@@ -1062,7 +970,6 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
   RDM_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.Wt & 15) == 0, "conv: operands must be 16-byte aligned");
   RDM_CHECK_ARG(a.g.dir == 1 || (a.g.SH == 1 && a.g.SW == 1), "dgrad gather supports stride 1 only");
   RDM_CHECK_ARG(a.M == a.g.B * a.g.Ho * a.g.Wo, "conv: M (%d) != B*Ho*Wo", a.M);
-  RDM_CHECK_ARG(a.A2 == nullptr || (b_kstrided && a.aff_a && a.aff_b && a.aff_c && a.g.KH == 1 && a.g.KW == 1), "conv: the BN-backward prologue is built for 1x1 dgrad only");
   const bool taps = !(a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 &&
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const long kslabs = (long)(a.C / 16) * (taps ? a.g.KH * a.g.KW : 1);
@@ -1103,7 +1010,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
 
   const bool halo_fwd = !b_kstrided && a.g.dir == 1, halo_dgrad = b_kstrided && a.g.dir == -1;
   if ((halo_fwd || halo_dgrad) && g_variant != 7 && taps && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 && a.g.PW == 1 &&
-      a.g.H == a.g.Ho && a.g.W == a.g.Wo && 2 * (a.g.W + 1) <= 256 && a.A2 == nullptr &&   // halo <= 512 pixels = 8 float4 per thread
+      a.g.H == a.g.Ho && a.g.W == a.g.Wo && 2 * (a.g.W + 1) <= 256 &&   // halo <= 512 pixels = 8 float4 per thread
       (long)a.g.B * a.g.H * a.g.W < (1L << 30)) {
     prof.kind = halo_dgrad ? 3 : 2;
     // LDS halo kernel; K is split over whole channel slabs (a split keeps its 9-tap groups together).
@@ -1169,7 +1076,6 @@ static void launch_wgrad_cfg(const WgradArgs& a, bool taps, hipStream_t s) {
   const long padded = (b.n_items + 7) / 8 * 8;               // whole groups of 8 so every (item, tap) pair exists
   dim3 grid((unsigned)(taps ? padded * ntaps : b.n_items));
   if (taps) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(256), 0, s, b);
-  else if (b.G2 != nullptr) hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false, true>), grid, dim3(256), 0, s, b);
   else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, b);
 }
 
@@ -1195,7 +1101,6 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   RDM_CHECK_ARG(a.N % 4 == 0 && a.C % 4 == 0, "wgrad: N (%d) and C (%d) must be multiples of 4", a.N, a.C);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0, "wgrad: strides must be multiples of 4 floats");
   RDM_CHECK_ARG(((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "wgrad: operands must be 16-byte aligned");
-  RDM_CHECK_ARG(a.G2 == nullptr || (a.aff_a && a.aff_b && a.aff_c && a.g.KH == 1 && a.g.KW == 1), "wgrad: the BN-backward prologue is built for 1x1 convs only");
   const bool taps = !(a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 &&
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const int ntaps = taps ? a.g.KH * a.g.KW : 1;
@@ -1211,7 +1116,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
                      narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : tall ? (long)cdiv(a.C, 48) * cdiv(a.N, 256) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
   // 3x3 / stride 1 / pad 1 with few output channels: the row kernel (3 taps per block)
   const bool row3 = g_variant != 9 && kslabs >= 1024 && a.N <= 96 &&   // long K only: at M <= 4560 the generic kernel's finer tiles win (A/B)
-                    a.G2 == nullptr && a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
+                    a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
                     a.g.PW == 1 && a.g.H == a.g.Ho && a.g.W == a.g.Wo && a.g.dir == 1;
   if (a.split_k <= 0) a.split_k = row3 ? pick_split_row3((long)cdiv(a.C, 256) * cdiv(a.N, 48), kslabs) : pick_split_k(tiles, kslabs, 256 * 3);
   {

@@ -108,7 +108,7 @@ struct NetImpl {
   std::vector<LayerWs> lws[4];
   size_t transP[3], transBn[3];
   // backward scratch
-  size_t G[4], dZ[2], dZ1, cA, cB, cC, c2[2], dP, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
+  size_t G[4], dZ[2], dZ1, cA, cB, cC, dP, gE1, dWstem, dL, tmp64, bwd_stats_begin, bwd_stats_end, transBs[3];
   // weight gradients run on a library-owned side stream, fenced with events against the caller's
   // stream: wgrad of a layer only depends on tensors that are final when its dgrad chain starts
   hipStream_t side = nullptr;
@@ -202,7 +202,6 @@ struct NetImpl {
     for (int t = 0; t < 3; ++t) transBs[t] = a.take<double>(2 * (size_t)kTrans[t].cin);
     bwd_stats_end = a.take<double>(0);
     cA = a.take<float>(maxC); cB = a.take<float>(maxC); cC = a.take<float>(maxC);
-    c2[0] = a.take<float>(3 * maxC); c2[1] = a.take<float>(3 * maxC);      // norm2 backward coefficients, double-buffered with dZ
     dP = a.take<float>(maxP);
     gE1 = a.take<float>((size_t)M1 * 96);
     dWstem = a.take<float>(96 * 160);
@@ -223,7 +222,6 @@ ConvGeom geom3x3(int B, int H, int W, int dir) { return ConvGeom{B, H, W, H, W, 
 // statistics of rows of a matrix are fused in the conv epilogue on big layers; split-K layers
 // (few rows) reduce with a separate pass
 inline bool fuse_stats(int M, int N) {
-  if (g_variant == 18 && M <= 8192) return (long)cdiv(M, 128) * cdiv(N, 48) >= 256;      // experiment: small-M layers unsplit with fused statistics
   return (long)cdiv(M, 256) * cdiv(N, 48) >= 1536;   // flat between 512 and 3072 (swept)
 }
 
@@ -357,7 +355,6 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
   float* blk = at<float>(ws, n.blk[b]);
   float* G = at<float>(ws, n.G[b]);
   float* dZ1 = at<float>(ws, n.dZ1);
-  float* cA = at<float>(ws, n.cA); float* cB = at<float>(ws, n.cB); float* cC = at<float>(ws, n.cC);
   int rc;
   if ((rc = n.ensure_side())) return rc;
   hipStream_t side = n.side;
@@ -398,17 +395,10 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
     if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
-    float* q2 = at<float>(ws, n.c2[par]);
-    float* qa = q2, *qb = q2 + cb, *qc = q2 + 2 * cb;
-    // shipped: one elementwise pass dZ := dY (coefficients computed in the same kernel).  Variant 2 forms dY inside the
-    // conv1 dgrad/wgrad loaders instead (no extra pass, but the heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
-    const bool materialise = g_variant != 2;
-    if (materialise) {
-      if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,
-                                    Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s)))
-        return rc;
-    } else if ((rc = launch_bn_bwd_coeffs(s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb, qa, qb, qc,
-                                          Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, cb, training, s)))
+    // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
+    // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
+    if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,
+                                  Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s)))
       return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
@@ -418,7 +408,6 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
       WgradArgs w{};
       w.g = geom1x1(n.B, g.H, g.W);
       w.G = dZ; w.ldg = cb; w.N = cb;
-      if (!materialise) { w.G2 = Y; w.aff_a = qa; w.aff_b = qb; w.aff_c = qc; }
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
       if ((rc = launch_conv_wgrad(w, side))) return rc;
@@ -431,7 +420,6 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
     FwdArgs e{};
     e.g = geom1x1(n.B, g.H, g.W);
     e.A = dZ; e.lda = cb; e.C = cb;
-    if (!materialise) { e.A2 = Y; e.aff_a = qa; e.aff_b = qb; e.aff_c = qc; }
     e.Wt = F(T, L.conv1); e.wtap = 0; e.ldw = cin;
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;

@@ -57,9 +57,6 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   ConvGeom g;
   const float* A; int lda; int C;             // contracted channels per tap (multiple of 16)
   const float* a_scale; const float* a_shift; // optional BN-ReLU prologue on A (per contracted channel)
-  // optional BatchNorm-backward prologue (dgrad of the conv that FOLLOWS a BN): the operand is formed on the
-  // fly as aff_a[c]*A + aff_b[c]*A2 + aff_c[c] (A = ReLU-gated dz, A2 = the BN's forward input, same geometry)
-  const float* A2; const float* aff_a; const float* aff_b; const float* aff_c;
   const float* Wt; long wtap; int ldw;        // weight tap stride / row stride (floats)
   float* out; int ldc; int M, N;
   const float* bias;                          // EPI_STORE only
@@ -74,7 +71,6 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
 struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)][c])
   ConvGeom g;
   const float* G; int ldg; int N;             // gradient wrt conv output, rows n
-  const float* G2; const float* aff_a; const float* aff_b; const float* aff_c;   // optional: G := aff_a[n]*G + aff_b[n]*G2 + aff_c[n]
   const float* Xs; int ldx; int C;            // forward conv input (pre BN-ReLU), rows c
   const float* x_scale; const float* x_shift; // optional BN-ReLU prologue (per c)
   float* dW; long wtap; int ldw;              // pre-zeroed, atomically accumulated
