@@ -70,3 +70,32 @@ def test_blend_extrapolation_saturates_like_pillow():
         for f in (0.0, 0.6, 1.0, 1.4, 2.5):
             ref = np.asarray(enh(Image.fromarray(rgb, "RGB")).enhance(f))
             assert np.array_equal(ref, P.np_color_jitter(rgb, [(name, f)])), (name, f)
+
+
+def test_host_side_parameters_match_the_oracle_conventions():
+    """md_rdm_amd.dataloaders.nyu.make_params (host logic of the GPU pipeline, importable without a GPU): Resize sizes,
+    centre-crop origin and the 16.16 fixed-point rotation coefficients are the ones the Pillow-pinned oracle derives."""
+    from md_rdm_amd.dataloaders import nyu
+    rng = np.random.default_rng(4)
+    for (H, W, out) in [(480, 640, (228, 304)), (375, 1242, (228, 304)), (300, 300, (228, 228)), (640, 480, (228, 228))]:
+        for _ in range(8):
+            s, ang = float(rng.uniform(1.0, 1.5)), float(rng.uniform(-5, 5))
+            p = nyu.make_params(s, ang, True, [("contrast", 0.9)], (H, W), 250, out)
+            h1, w1 = P.resized_hw(H, W, 250)
+            assert (h1, w1) == nyu.resized_hw(H, W, 250)
+            h2, w2 = P.resized_hw(h1, w1, int(250 * s))
+            assert (p.h2, p.w2) == (h2, w2)
+            assert (p.top, p.left) == P.center_crop_box(h2, w2, *out)
+            assert list(p.rot) == list(P.affine_fixed_coeffs(P.rotate_matrix(ang, w1, h1)))
+            assert p.flip == 1 and list(p.op) == [1, -1, -1] and abs(p.depth_div - s) < 1e-6
+    ident = nyu.identity_params((480, 640), 250, (228, 304))
+    assert list(ident.rot) == [65536, 0, 32768, 0, 65536, 32768] and (ident.h2, ident.w2) == (250, 333) and list(ident.op) == [-1, -1, -1]
+    d, p = nyu.draw_training_params(np.random.default_rng(0), (480, 640))
+    assert 1.0 <= d["s"] <= 1.5 and -5.0 <= d["angle"] <= 5.0 and sorted(n for n, _ in d["jitter"]) == ["brightness", "contrast", "saturation"]
+    with pytest.raises(ValueError):
+        nyu.make_params(0.9, 0.0, False, [], (480, 640), 250, (228, 304))
+    raws = [(np.zeros((480, 640, 3), np.uint8), np.ones((480, 640), np.float32))] * 3
+    ds = nyu.NYUDataset(raws, split="val")
+    assert len(ds) == 3 and ds.get_raw(1)[0].shape == (480, 640, 3)
+    with pytest.raises(RuntimeError):
+        nyu.NYUDataset(raws, split="bogus")
