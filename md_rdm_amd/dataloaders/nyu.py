@@ -1,7 +1,7 @@
 """NYU-v2 input pipeline, MI355X-first (reference: dataloaders/nyu_dataloader.py, dataloaders/dataloader.py).
 
 The reference decodes one sample per DataLoader worker and runs ~10 PIL operations on it on the CPU
-(``training_preprocess`` :240-272).  At 190 images/s per GPU (8 GPUs: 1500/s) that needs ~25 busy host
+(``training_preprocess`` :240-272; measured 131 images/s per core).  At 200 images/s per GPU (8 GPUs: 1600/s) that needs ~12 busy host
 cores; here the host only reads the raw uint8 / float32 arrays into pinned memory, and the whole
 augmentation chain runs as a handful of batch-wide HIP launches (``rdm_nyu_preprocess``), bit-exact
 with the Pillow arithmetic of the reference for given random draws.
