@@ -185,7 +185,7 @@ int rdm_depth_metrics_f64(const double* pred, const double* target, int64_t n, d
  * one rdm_nyu_aug per sample, in DEVICE memory (md_rdm_amd/dataloaders/nyu.py fills it).
  *   rgb (B,in_h,in_w,3) uint8, depth (B,in_h,in_w) float32  ->  x (B,3,out_h,out_w), y (B,1,out_h,out_w) float32
  *   (resized_h, resized_w) = torchvision Resize(resize) of (in_h, in_w); validation = identity augmentation
- *   (depth_div 1, rot {65536,0,32768,0,65536,32768}, h2/w2 = resized size, ops -1).
+ *   (depth_div 1, rot {65536,0,32768,0,65536,32768}, h2/w2 = resized size, ops -1, crop2 = {0,0,resized_h,resized_w}).
  * ------------------------------------------------------------------------------------------ */
 typedef struct rdm_nyu_aug {
   float depth_div;      /* s: depth / s (:241-242) */
@@ -195,6 +195,8 @@ typedef struct rdm_nyu_aug {
   int32_t flip;         /* hflip (:264-266) */
   int32_t op[3];        /* ColorJitter order: 0 brightness, 1 contrast, 2 saturation, -1 none (:247) */
   float factor[3];      /* and the enhancement factors */
+  int32_t crop2[4];     /* window {top, left, height, width} of the rotated image that the second Resize reads: the whole image for
+                           train / val; test_preprocess (:289-307) = Resize(500), CenterCrop((480, 640)) as crop2, Resize(output_size) */
 } rdm_nyu_aug;
 size_t rdm_nyu_preprocess_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h, int32_t resized_w, int32_t out_w);
 int rdm_nyu_preprocess(const uint8_t* rgb, const float* depth, const rdm_nyu_aug* aug, int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h,

@@ -29,8 +29,9 @@ struct NyuAug {            // mirrors rdm_nyu_aug (include/rdm_hip.h)
   int h2, w2, top, left, flip;
   int op[3];
   float factor[3];
+  int crop2[4];            // region of the rotated image the second Resize reads: top, left, height, width
 };
-static_assert(sizeof(NyuAug) == 72, "rdm_nyu_aug layout");
+static_assert(sizeof(NyuAug) == 88, "rdm_nyu_aug layout");
 
 constexpr int KMAX = 9;    // taps of the antialiased triangle filter for a down-scale of up to 4
 
@@ -129,10 +130,14 @@ __global__ __launch_bounds__(256) void k_resample_h(const unsigned char* __restr
   if (c >= ncols) return;
   const int out_w = SECOND ? aug[b].w2 : out_w_uniform;
   const int xx = (SECOND ? aug[b].left : 0) + c;
+  // SECOND: the pass reads the crop2 window of the (rows x in_w) image: row y of the window, columns from crop2.left
+  const int src_w = SECOND ? aug[b].crop2[3] : in_w;
+  if (SECOND && y >= aug[b].crop2[2]) return;
+  const long src_row = SECOND ? (long)(aug[b].crop2[0] + y) * in_w + aug[b].crop2[1] : (long)y * in_w;
   Coef k;
-  bilinear_coeffs(in_w, out_w, xx, k);
-  const unsigned char* rp = rgb_in + ((long)b * rows + y) * in_w * 3;
-  const float* dp = dep_in + ((long)b * rows + y) * in_w;
+  bilinear_coeffs(src_w, out_w, xx, k);
+  const unsigned char* rp = rgb_in + ((long)b * rows * in_w + src_row) * 3;
+  const float* dp = dep_in + (long)b * rows * in_w + src_row;
   const float div = first_divide ? aug[b].depth_div : 1.0f;
   int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
   double sd = 0.0;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void k_resample_v_final(const unsigned char* _
   const int b = blockIdx.z, r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
   Coef k;
-  bilinear_coeffs(in_h, aug[b].h2, aug[b].top + r, k);
+  bilinear_coeffs(aug[b].crop2[2], aug[b].h2, aug[b].top + r, k);     // rows of the crop2 window (t4 holds them from row 0)
   const unsigned char* rp = rgb_in + (long)b * in_h * cols * 3 + (long)c * 3;
   const float* dp = dep_in + (long)b * in_h * cols + c;
   int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
@@ -253,7 +258,6 @@ int launch_nyu_preprocess(const unsigned char* rgb, const float* depth, const vo
                           float* x, float* y, void* ws, size_t ws_bytes, hipStream_t s) {
   RDM_CHECK_ARG(rgb && depth && aug_dev && x && y && ws, "nyu_preprocess: null pointer");
   RDM_CHECK_ARG(B > 0 && H > 0 && W > 0 && h1 > 0 && w1 > 0 && oh > 0 && ow > 0, "nyu_preprocess: sizes must be positive");
-  RDM_CHECK_ARG(h1 >= oh && w1 >= ow, "nyu_preprocess: centre crop %dx%d larger than the resized image %dx%d", oh, ow, h1, w1);
   RDM_CHECK_ARG((long)H <= 4L * h1 && (long)W <= 4L * w1, "nyu_preprocess: down-scale beyond 4x (%dx%d -> %dx%d) exceeds the %d-tap filter window", H, W, h1, w1, KMAX);
   RDM_CHECK_ARG(B <= 65535 && H <= 65535, "nyu_preprocess: batch / height exceed the grid limits");
   RDM_CHECK_ARG(h1 < 16384 && w1 < 16384, "nyu_preprocess: the 16.16 fixed-point rotation needs images below 16384 pixels per side");

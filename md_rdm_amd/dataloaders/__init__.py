@@ -1,2 +1,2 @@
 """Input pipeline: the reference's dataloaders/ with the per-sample PIL work moved to the GPU."""
-from .nyu import NYUDataset, NyuGpuPreprocessor, PrefetchLoader, draw_training_params, identity_params  # noqa: F401
+from .nyu import NYUDataset, NyuGpuPreprocessor, PrefetchLoader, draw_training_params, identity_params, test_params  # noqa: F401

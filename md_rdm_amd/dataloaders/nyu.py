@@ -31,7 +31,7 @@ _OPS = {"brightness": 0, "contrast": 1, "saturation": 2}
 class NyuAug(C.Structure):
     """rdm_nyu_aug (include/rdm_hip.h)"""
     _fields_ = [("depth_div", C.c_float), ("rot", C.c_int32 * 6), ("h2", C.c_int32), ("w2", C.c_int32), ("top", C.c_int32),
-                ("left", C.c_int32), ("flip", C.c_int32), ("op", C.c_int32 * 3), ("factor", C.c_float * 3)]
+                ("left", C.c_int32), ("flip", C.c_int32), ("op", C.c_int32 * 3), ("factor", C.c_float * 3), ("crop2", C.c_int32 * 4)]
 
 
 def resized_hw(h, w, size):
@@ -77,6 +77,24 @@ def make_params(s, angle, flip, jitter, in_hw, resize, output_size):
     for i, (name, f) in enumerate(ops[:3]):
         p.op[i] = _OPS[name] if name is not None else -1
         p.factor[i] = f
+    p.crop2[:] = [0, 0, h1, w1]
+    return p
+
+
+def test_params(in_hw, output_size):
+    """test_preprocess (:289-307): Resize(500) -> CenterCrop((480, 640)) -> Resize(output_size) to the exact (h, w).
+    Use with ``NyuGpuPreprocessor(resize=500, output_size=output_size)``."""
+    h1, w1 = resized_hw(in_hw[0], in_hw[1], 500)
+    if h1 < 480 or w1 < 640:
+        raise ValueError(f"CenterCrop((480, 640)) larger than the resized image {(h1, w1)}")
+    p = NyuAug()
+    p.depth_div = 1.0
+    p.rot[:] = _rotation_fixed(0.0, w1, h1)
+    p.h2, p.w2 = output_size
+    p.top = p.left = p.flip = 0
+    for i in range(3):
+        p.op[i], p.factor[i] = -1, 1.0
+    p.crop2[:] = [int(round((h1 - 480) / 2.0)), int(round((w1 - 640) / 2.0)), 480, 640]
     return p
 
 
@@ -179,7 +197,7 @@ class PrefetchLoader:
         self.rng = np.random.default_rng(seed + rank)
         self.order_rng = np.random.default_rng(seed)            # same permutation on every rank, disjoint shards
         self.rank, self.world, self.drop_last = rank, world, drop_last
-        self.pre = NyuGpuPreprocessor(dataset.resize, dataset.output_size, device)
+        self.pre = NyuGpuPreprocessor(500 if dataset.split == "test" else dataset.resize, dataset.output_size, device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
 
     def __len__(self):
@@ -196,6 +214,8 @@ class PrefetchLoader:
             dep[j] = torch.from_numpy(d)
         if self.train:
             params = [draw_training_params(self.rng, (H, W), self.ds.resize, self.ds.output_size)[1] for _ in idx]
+        elif self.ds.split == "test":
+            params = [test_params((H, W), self.ds.output_size) for _ in idx]
         else:
             params = [identity_params((H, W), self.ds.resize, self.ds.output_size) for _ in idx]
         return rgb, dep, params

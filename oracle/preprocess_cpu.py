@@ -116,6 +116,22 @@ def pil_validation_preprocess(rgb, depth, resize=250, output_size=(228, 304)):
     return x, y
 
 
+def pil_test_preprocess(rgb, depth, output_size=(228, 304)):
+    """nyu_dataloader.py:289-307: Resize(500) -> CenterCrop((480, 640)) -> Resize(output_size) [a (h, w) tuple: exact size]."""
+    from PIL import Image
+    rgb_i = _pil_resize(Image.fromarray(rgb, "RGB"), 500)
+    dep_i = _pil_resize(Image.fromarray(np.asarray(depth, dtype=np.float32), "F"), 500)
+    w, h = rgb_i.size
+    top, left = center_crop_box(h, w, 480, 640)
+    box = (left, top, left + 640, top + 480)
+    rgb_i, dep_i = rgb_i.crop(box), dep_i.crop(box)
+    size = (output_size[1], output_size[0])
+    rgb_i, dep_i = rgb_i.resize(size, Image.BILINEAR), dep_i.resize(size, Image.BILINEAR)
+    x = np.asarray(rgb_i, dtype=np.uint8).transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+    y = np.asarray(dep_i, dtype=np.float32)[None]
+    return x, y
+
+
 # ---------------------------------------------------------------------------------------------
 # layer 2: numpy restatement of the Pillow C code
 # ---------------------------------------------------------------------------------------------
@@ -262,4 +278,14 @@ def np_validation_preprocess(rgb, depth, resize=250, output_size=(228, 304)):
     top, left = center_crop_box(nh, nw, *output_size)
     rgb = rgb[top:top + output_size[0], left:left + output_size[1]]
     depth = depth[top:top + output_size[0], left:left + output_size[1]]
+    return rgb.transpose(2, 0, 1).astype(np.float32) / np.float32(255), np.ascontiguousarray(depth)[None]
+
+
+def np_test_preprocess(rgb, depth, output_size=(228, 304)):
+    h, w = rgb.shape[:2]
+    nh, nw = resized_hw(h, w, 500)
+    rgb, depth = np_resize(rgb, nh, nw), np_resize(np.asarray(depth, np.float32), nh, nw)
+    top, left = center_crop_box(nh, nw, 480, 640)
+    rgb, depth = rgb[top:top + 480, left:left + 640], depth[top:top + 480, left:left + 640]
+    rgb, depth = np_resize(np.ascontiguousarray(rgb), *output_size), np_resize(np.ascontiguousarray(depth), *output_size)
     return rgb.transpose(2, 0, 1).astype(np.float32) / np.float32(255), np.ascontiguousarray(depth)[None]

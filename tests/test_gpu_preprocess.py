@@ -63,6 +63,19 @@ def test_validation_preprocess_bit_exact_and_loader():
         assert np.array_equal(x[i], xr) and np.array_equal(y[i], yr)
 
 
+def test_test_preprocess_bit_exact_through_the_loader():
+    """split="test": Resize(500) -> CenterCrop((480, 640)) -> Resize(output_size) (nyu_dataloader.py:289-307)."""
+    from md_rdm_amd.dataloaders import nyu
+    rng = np.random.default_rng(15)
+    raws = [_sample(rng, 480, 640, smooth=i == 0) for i in range(3)]
+    for out in [(228, 304), (226, 226)]:
+        ds = nyu.NYUDataset(raws, split="test", output_size=out)
+        x, y = next(iter(nyu.PrefetchLoader(ds, batch_size=3, drop_last=False)))
+        for i, (rgb, depth) in enumerate(raws):
+            xr, yr = P.pil_test_preprocess(rgb, depth, output_size=out)
+            assert np.array_equal(x[i].cpu().numpy(), xr) and np.array_equal(y[i].cpu().numpy(), yr)
+
+
 def test_training_loader_shards_and_reproduces_its_draws():
     from md_rdm_amd.dataloaders import nyu
     rng = np.random.default_rng(9)

@@ -99,3 +99,13 @@ def test_host_side_parameters_match_the_oracle_conventions():
     assert len(ds) == 3 and ds.get_raw(1)[0].shape == (480, 640, 3)
     with pytest.raises(RuntimeError):
         nyu.NYUDataset(raws, split="bogus")
+
+
+def test_test_preprocess_matches_pillow():
+    """nyu_dataloader.py:289-307: Resize(500) -> CenterCrop((480, 640)) -> Resize((h, w))."""
+    rng = np.random.default_rng(12)
+    for out in [(228, 304), (226, 226)]:
+        rgb, depth = _sample(rng, 480, 640, smooth=out[0] == 228)
+        x1, y1 = P.pil_test_preprocess(rgb, depth, output_size=out)
+        x2, y2 = P.np_test_preprocess(rgb, depth, output_size=out)
+        assert x1.shape == (3,) + out and np.array_equal(x1, x2) and np.array_equal(y1, y2)
