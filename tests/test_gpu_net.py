@@ -184,6 +184,27 @@ def test_full_size_properties_b16_228x304(dev):
     assert dict(m.named_parameters())["encoder.conv_e1.weight"].grad.abs().max() > 0
 
 
+def test_kitti_geometry_b8_352x1216(dev):
+    """BASELINE config 5 (wide aspect, 11x38 head; the reference's own forward raises past the DORN head there): same
+    size-independent properties, plus the 38-wide maps exercise the 256-pixel halo tiles with a 6-load halo run."""
+    B, H, W = 8, 352, 1216
+    x, y = filler.synthetic_batch(B, H, W, seed=77)
+    xg = torch.from_numpy(x).to(dev)
+    m = make_model(dev, train=False)
+    with torch.no_grad():
+        _, dec, P = m(xg)
+        _, dec1, P1 = m(xg[5:6].contiguous())
+    assert tuple(P.shape) == (B, 90, 11, 38) and tuple(dec.shape) == (B, 1, 11, 38)
+    assert P.min() >= 0 and P.max() <= 1 and torch.equal(dec, (P > 0.5).sum(1, keepdim=True))
+    np.testing.assert_allclose(P[5:6].cpu().numpy(), P1.cpu().numpy(), atol=5e-5)
+    m.train()
+    y_hat, x_d1, ord_labels = m(xg)
+    (ord_labels.float() ** 2).mean().backward()                     # gradient of the conv stack through the DORN head
+    g = dict(m.named_parameters())
+    for n in ["encoder.conv_e1.weight", "encoder.dense_e2.denselayer3.conv2.weight", "encoder.dense_e4.denselayer30.norm1.weight", "d_1.conv2.weight"]:
+        assert g[n].grad is not None and torch.isfinite(g[n].grad).all() and g[n].grad.abs().max() > 0, n
+
+
 def test_state_dict_roundtrip_and_reflatten(dev):
     """Checkpoints interchange (968 reference keys); .to()/load_state_dict keep the native plan coherent."""
     a = make_model(dev, train=False)
