@@ -57,6 +57,8 @@ def main(argv=None):
     parser.add_argument("--nyu_path", type=str, default=None)
     parser.add_argument("--synthetic", action="store_true")
     parser.add_argument("--size", type=int, nargs=2, default=[226, 226], help="input HxW (module.py:19 feeds 226x226)")
+    parser.add_argument("--checkpoint_dir", type=str, default=None, help="keep the best checkpoint by val_delta1 here (train.py:41-47: ModelCheckpoint(save_top_k=1, monitor='val_delta1', mode='max'))")
+    parser.add_argument("--resume", type=str, default=None, help="Lightning .ckpt or state_dict to start from")
     parser.add_argument("--relative_decoders", type=int, nargs="*", default=[], help="subset of 6 7 8 9: the relative decoders the reference keeps commented out (RDM_Net.py:57-60)")
     args = parser.parse_args(argv)
     if args.precision != 32:
@@ -80,8 +82,12 @@ def main(argv=None):
     from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
     model = DepthEstimationNet(relative_decoders=tuple(args.relative_decoders)).to(dev)
+    if args.resume:
+        from .checkpoint import from_lightning
+        from_lightning(model, args.resume)
     model.flatten_parameters()
     sync = parallel.attach(model)
+    best_delta1, best_path = None, None
     opt = harness.FusedAdamW(model, lr=args.learning_rate)
     sched = ReduceLROnPlateau(opt, "max", patience=2)
     logger = MetricLogger(args.metrics if "delta1" in args.metrics else ["delta1"] + list(args.metrics))
@@ -136,6 +142,14 @@ def main(argv=None):
                 logger.log_val(y_hat, y_n)
         d1 = logger.computer.avg("delta1")         # epoch mean of the per-step values, as Lightning's self.log aggregates val_delta1
         sched.step(d1)
+        if args.checkpoint_dir and rank == 0 and (best_delta1 is None or d1 > best_delta1):     # save_top_k=1, mode='max'
+            from .checkpoint import to_lightning
+            os.makedirs(args.checkpoint_dir, exist_ok=True)
+            path = os.path.join(args.checkpoint_dir, f"epoch={epoch}-val_delta1={d1:.4f}.ckpt")
+            torch.save(to_lightning(model, {"epoch": epoch, "global_step": (epoch + 1) * steps}), path)
+            if best_path and best_path != path and os.path.exists(best_path):
+                os.remove(best_path)
+            best_delta1, best_path = d1, path
         if rank == 0:
             print(f"epoch {epoch}: {steps * args.batch_size * world / (time.time() - t0):.1f} img/s, val_delta1 {d1:.4f}, lr {opt.lr:g}", flush=True)
     if world > 1:

@@ -123,10 +123,16 @@ def test_train_script_on_a_raw_dataset(tmp_path, capsys):
         for i in range(n):
             rgb, depth = _sample(rng, 480, 640, smooth=True)
             np.savez(d / f"{i:05d}.npz", rgb=rgb, depth=depth + 0.5)
-    train.main(["--nyu_path", str(tmp_path), "--batch_size", "2", "--max_epochs", "1", "--seed", "1"])
+    ck = tmp_path / "ck"
+    train.main(["--nyu_path", str(tmp_path), "--batch_size", "2", "--max_epochs", "2", "--seed", "1", "--checkpoint_dir", str(ck)])
     out = capsys.readouterr().out
     assert "epoch 0 step 1 loss" in out and "val_delta1" in out
     assert "nan" not in out.lower()
+    saved = list(ck.glob("*.ckpt"))
+    assert len(saved) == 1                                           # save_top_k = 1
+    state = torch.load(saved[0], map_location="cpu")["state_dict"]
+    assert len(state) == 968 and all(k.startswith("model.") for k in state)
+    train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1", "--resume", str(saved[0])])
 
 
 def test_train_script_synthetic_dev_run(capsys):
