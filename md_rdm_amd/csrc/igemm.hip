@@ -123,6 +123,7 @@ __device__ __forceinline__ void conv_epilogue(const FwdArgs& p, f32x4 (&acc)[MT]
           if (EPI == EPI_STORE) {
             *dst = v + bias;
           } else if (EPI == EPI_STORE_STATS) {
+            if (p.add_out) v += *dst;            // this launch holds the LAST K-partial of the element: finish the sum, then reduce
             *dst = v;
             s0 += v; s1 += v * v;
           } else if (EPI == EPI_MASK_STATS) {

@@ -238,7 +238,7 @@ int finalize_norm1(NetImpl& n, int b, int i, int c_lo, int c_hi, bool count_batc
 }
 
 // conv1 (1x1) of layer i over the input channels [c_lo, c_hi); accumulate => atomically added into a zeroed Y
-int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, bool fuse, void* ws, void* const* T, hipStream_t s) {
+int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, bool fuse, void* ws, void* const* T, hipStream_t s, bool add_out = false) {
   const BlockGeom& g = n.bg[b];
   const LayerIdx& L = reg().layers[b][i];
   const LayerWs& W = n.lws[b][i];
@@ -252,6 +252,7 @@ int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, b
   a.out = at<float>(ws, W.Y); a.ldc = g.cb; a.M = g.M; a.N = g.cb;
   a.stat0 = sty; a.stat1 = sty + g.cb;
   a.accumulate = accumulate ? 1 : 0;
+  a.add_out = add_out ? 1 : 0;
   const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
   return rc < 0 ? rc : 0;
 }
@@ -287,15 +288,21 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     }
     // ---- main: conv1 of layer i ----
     const bool fuse = training && fuse_stats(g.M, g.cb);
+    bool stats_done = false;
     if (pipelined && i > 0) {
       if ((rc = finalize_norm1(n, b, i, cin - GROWTH, cin, false, ws, T, training, s))) return rc;
       RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_fa[i & 1], 0));
-      if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, true, false, ws, T, s))) return rc;
+      if (training && g_variant != 36) {
+        // part B is three K-slabs and runs unsplit: its epilogue adds part A's finished sum, stores the final value and takes
+        // the channel statistics of it - no separate reduction pass over Y on the critical path (it took 56 us beside part A)
+        if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, false, true, ws, T, s, true))) return rc;
+        stats_done = true;
+      } else if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, true, false, ws, T, s))) return rc;
     } else {
       if ((rc = finalize_norm1(n, b, i, 0, cin, true, ws, T, training, s))) return rc;
       if ((rc = conv1_range(n, b, i, 0, cin, false, fuse, ws, T, s))) return rc;
     }
-    if (training && !fuse && (rc = launch_colstats(Y, g.cb, g.M, g.cb, sty, sty + g.cb, s))) return rc;
+    if (training && !fuse && !stats_done && (rc = launch_colstats(Y, g.cb, g.M, g.cb, sty, sty + g.cb, s))) return rc;
     if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
                                  static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
       return rc;

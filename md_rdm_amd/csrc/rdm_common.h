@@ -64,6 +64,7 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   const float* X; int ldx; const float* x_scale; const float* x_shift;  // MASK_STATS: forward pre-BN value + its affine
   int split_k;                                // >1 => EPI_ATOMIC into pre-zeroed out
   int xcd_flat;                               // 1: keep the hardware block order (A/B switch; default 0 = XCD-aware order)
+  int add_out;                                // EPI_STORE_STATS: out = out + v (the statistics are taken of the SUM): completes a K-partial
   int accumulate;                             // 1: add into `out` (f32 atomics), never zero it - the caller owns the initial value
   unsigned a_bytes, w_bytes;                  // set by the launcher: addressable extents of A / Wt (buffer descriptors)
 };
