@@ -2,6 +2,8 @@
 restated without Lightning so that it runs on this stack: same target preparation, same loss sum,
 AdamW(lr) as in ``configure_optimizers`` (:38-47).  ``train.py``'s flags are mirrored in
 md_rdm_amd/train.py."""
+import ctypes as C
+
 import torch
 
 from . import loss as l
@@ -80,6 +82,26 @@ class FusedAdamW:
     def zero_grad(self):
         self.small.zero_grad(set_to_none=True)
 
+    def trainable_ranges(self):
+        """Maximal contiguous [start, stop) element ranges of the flat buffer that hold tensors which receive a gradient.
+        torch.optim.AdamW (the reference's optimiser) skips every parameter whose ``.grad is None``: ``d_1.conv1.*`` (constructed
+        for every decoder, used only for id > 5, RDM_Net.py:146,156-157) and whatever ``freeze_encoder()`` froze (:65-67) must
+        stay bit-unchanged - no weight decay, no moments.  Alignment padding between two trainable tensors is swept along
+        (parameter, gradient and moments are all zero there and stay zero)."""
+        _, _, entries = self.model._flat
+        key = tuple(p.requires_grad for _, p, _, _, _ in entries)
+        if getattr(self, "_ranges_key", None) != key:
+            ranges = []
+            for k, p, o, n, _ in entries:
+                if not p.requires_grad or k.startswith("d_1.conv1."):
+                    continue
+                if ranges and ranges[-1][2] == o:                 # previous trainable tensor (padded to its 64-float slot) ends here
+                    ranges[-1][1], ranges[-1][2] = o + n, o + (n + 63) // 64 * 64
+                else:
+                    ranges.append([o, o + n, o + (n + 63) // 64 * 64])
+            self._ranges, self._ranges_key = [(a, b) for a, b, _ in ranges], key
+        return self._ranges
+
     def step(self, grad_scale=1.0):
         from . import _lib
         flat, gflat, _ = self.model._flat
@@ -87,6 +109,26 @@ class FusedAdamW:
             self.m = torch.zeros_like(flat)
             self.v = torch.zeros_like(flat)
         self.step_count += 1
-        _lib.check(_lib.lib().rdm_adamw_fused(_lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(self.m), _lib.ptr(self.v), flat.numel(), self.lr, self.betas[0],
-                                               self.betas[1], self.eps, self.wd, self.step_count, float(grad_scale), _lib.stream()))
+        L, st = _lib.lib(), _lib.stream()
+        for a, b in self.trainable_ranges():                      # 2 launches for the reference's live graph (around d_1.conv1)
+            off = C.c_void_p
+            _lib.check(L.rdm_adamw_fused(off(flat.data_ptr() + 4 * a), off(gflat.data_ptr() + 4 * a), off(self.m.data_ptr() + 4 * a),
+                                         off(self.v.data_ptr() + 4 * a), b - a, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                         self.step_count, float(grad_scale), st))
         self.small.step()
+
+    def state_dict(self):
+        """Moments, step and lr (the ``optimizer_states`` entry of a checkpoint)."""
+        return {"step": self.step_count, "lr": self.lr, "exp_avg": None if self.m is None else self.m.detach().cpu().clone(),
+                "exp_avg_sq": None if self.v is None else self.v.detach().cpu().clone(), "small": self.small.state_dict()}
+
+    def load_state_dict(self, sd):
+        flat = self.model._flat[0]
+        self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        if sd.get("exp_avg") is not None:
+            if sd["exp_avg"].numel() != flat.numel():
+                raise ValueError("optimizer state does not match the model's flat parameter buffer")
+            self.m, self.v = sd["exp_avg"].to(flat.device).clone(), sd["exp_avg_sq"].to(flat.device).clone()
+        self.small.load_state_dict(sd["small"])
+        for g in self.small.param_groups:
+            g["lr"] = self.lr

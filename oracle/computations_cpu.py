@@ -60,7 +60,21 @@ def _bicubic_matrix(n_in, n_out):
 
 def resize(depth_map, newsize):
     """computations.py:308-311: ``.double()`` + F.interpolate(size=newsize, bicubic,
-    align_corners=False).  An int ``newsize`` yields a SQUARE output whatever the input."""
+    align_corners=False).  An int ``newsize`` yields a SQUARE output whatever the input.
+    Bit-exact with the reference's torch CPU path: the rounding sequence is restated in
+    oracle/bicubic_aten.c (see its header); ``resize_matrix_form`` below is the same operator as two
+    dense matrices (1e-13 agreement, kept as an independent cross-check of the taps and weights)."""
+    from . import _native
+    x = np.ascontiguousarray(np.asarray(depth_map, dtype=np.float64))
+    if isinstance(newsize, int):
+        newsize = (newsize, newsize)
+    B, Cc, H, W = x.shape
+    out = np.empty((B, Cc, newsize[0], newsize[1]), dtype=np.float64)
+    _native.lib().rdm_oracle_resize_bicubic_f64(x.ctypes.data, out.ctypes.data, B * Cc, H, W, newsize[0], newsize[1])
+    return out
+
+
+def resize_matrix_form(depth_map, newsize):
     x = np.asarray(depth_map, dtype=np.float64)
     if isinstance(newsize, int):
         newsize = (newsize, newsize)
@@ -342,3 +356,21 @@ def relative_decoder_forward(x, decoder_id, tables=None):
         R, _ = lloyd_quantization(ratio_grid_raw(a, b), q, inv)
         filled.append(als_rank1(R, 4, 100)[0])
     return reconstruct(filled)
+
+
+def depth_metrics(pred, target, names=("delta1", "delta2", "delta3", "mse", "mae", "log10", "absrel", "sqrel", "rmse")):
+    """metrics.py:58-66 ``MetricComputation.compute`` (clamp pred to 1e-7, keep target > 0) with the metric functions of
+    metrics.py:79-116 ('rmse' is RelativeMeanSquareError, :107-110,128) and the library's mse / mae (pytorch_lightning 1.1.7
+    functional, third party: mean squared / absolute error).  Computed in the dtype of ``pred`` like the reference."""
+    pred = np.asarray(pred)
+    target = np.asarray(target).astype(pred.dtype)
+    p = np.maximum(pred, pred.dtype.type(1e-07))
+    m = target > 0
+    assert m.sum() > 0, "invalid target!"
+    p, t = p[m], target[m]
+    r = np.maximum(p / t, t / p)
+    f = {"delta1": lambda: (r < 1.25 ** 1).astype(np.float32).mean(), "delta2": lambda: (r < 1.25 ** 2).astype(np.float32).mean(),
+         "delta3": lambda: (r < 1.25 ** 3).astype(np.float32).mean(), "mse": lambda: ((p - t) ** 2).mean(), "mae": lambda: np.abs(p - t).mean(),
+         "log10": lambda: np.abs(np.log10(p) - np.log10(t)).mean(), "absrel": lambda: (np.abs(p - t) / t).mean(),
+         "sqrel": lambda: ((p - t) ** 2 / t).mean(), "rmse": lambda: np.sqrt((p - t) ** 2 / t).mean()}
+    return [float(f[n]()) for n in names]

@@ -2,12 +2,14 @@
 reference and (b) the oracle on the same seeded inputs.
 
 Forward tolerance: 1e-4 relative (north star), written as atol = 2e-4*max|ref| on logits / 2e-4 on
-probabilities; ordinal indices bit-exact wherever the reference's own pair margin exceeds the f32
-conv noise (1e-3), and never off by more than the number of such near-ties.
+probabilities; ordinal indices BIT-EXACT, asserted outright: the fixture inputs (filler.MARGIN_SEEDS)
+were chosen so that every ordinal pair decision of the reference has a margin of 25x the f32 conv noise.
 Backward: the loss surface is piecewise linear (ReLU, clamp); at B=2 the reference's own float32
 gradients deviate from a float64 evaluation by up to ~10 % on some tensors because single ReLU
-decisions flip (tests/test_oracle_net.py::test_f32_gradient_noise_floor documents it on CPU), so the
-criterion is: our error w.r.t. the float64 oracle is no larger than ~2x the float32 oracle's own."""
+decisions flip (tests/test_oracle_net.py::test_f32_gradient_noise_floor documents it on CPU).  The
+criterion is PER TENSOR: each tensor's error w.r.t. the float64 oracle is bounded by a multiple of THAT
+tensor's own float32-oracle error (no pooled maximum), and each tensor's gradient norm is held to the
+norm the reference itself produced (fixture train228_grad_norm, all 491 tensors)."""
 import numpy as np
 import pytest
 import torch
@@ -39,35 +41,32 @@ def make_model(dev, train=True):
     return m.train() if train else m.eval()
 
 
+SEED = filler.MARGIN_SEEDS
+
+
 def check_head(dec, P, gold_dec, gold_P, gold_logits):
-    margin = np.abs(np.clip(gold_logits[:, 1::2], 1e-8, 1e4) - np.clip(gold_logits[:, 0::2], 1e-8, 1e4))
-    risky = ((margin > 0) & (margin < 1e-3)).sum(1, keepdims=True)
-    safe = risky == 0
-    assert safe.mean() > 0.5
-    np.testing.assert_array_equal(dec[safe], gold_dec[safe])
-    assert np.abs(dec - gold_dec).max() <= risky.max()
+    assert filler.dorn_unsafe_pairs(gold_logits) == 0          # the fixture was built with margins (make_golden.py refuses otherwise)
+    np.testing.assert_array_equal(dec, gold_dec)               # ordinal indices: bit-exact, everywhere
     np.testing.assert_allclose(P, gold_P, atol=2e-4)
 
 
 def test_train_step_vs_reference_goldens(dev, net_gold):
     from md_rdm_amd import harness
     m = make_model(dev)
-    x, y = filler.synthetic_batch(2, 228, 228, seed=1234)
+    x, y = filler.synthetic_batch(2, 228, 228, seed=SEED["train228"])
     loss, parts = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
     for tap, (buf, c) in TAPS.items():
-        g = m.bg if False else None
         v = m.debug_buffer(buf)
         ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
         np.testing.assert_allclose(stats3(v.view(-1, ctot)[:, :c]), net_gold[f"train228_tap_{tap}"], rtol=1e-4, atol=1e-6)
     dec, P = parts["ord_depth_pred"].cpu().numpy(), parts["ord_label_pred"].detach().cpu().numpy()
     check_head(dec, P, net_gold["train228_decode_c"], net_gold["train228_ord_labels"], net_gold["train228_logits"])
     np.testing.assert_array_equal(parts["ord_y"].cpu().numpy(), net_gold["train228_ord_y"])
-    if np.array_equal(dec, net_gold["train228_decode_c"]):
-        for i in range(4):   # atol: log-domain values near log(1)=0 inherit the reference's own f32 geometric-mean rounding
-            np.testing.assert_allclose(parts["fine_details"][i].detach().cpu().numpy(), net_gold[f"train228_yhat{i}"], rtol=1e-4, atol=5e-6)
-        got = np.array([parts["mse"].item(), parts["fine_detail_loss"].item(), parts["ord_loss"].item(), loss.item()])
-        np.testing.assert_allclose(got, net_gold["train228_losses"], rtol=1e-4)
-        np.testing.assert_allclose(parts["final_depth"].detach()[:, :, :4, :4].cpu().numpy(), net_gold["train228_final_depth_corner"], rtol=1e-4, atol=1e-6)
+    for i in range(4):   # atol: log-domain values near log(1)=0 inherit the reference's own f32 geometric-mean rounding
+        np.testing.assert_allclose(parts["fine_details"][i].detach().cpu().numpy(), net_gold[f"train228_yhat{i}"], rtol=1e-4, atol=5e-6)
+    got = np.array([parts["mse"].item(), parts["fine_detail_loss"].item(), parts["ord_loss"].item(), loss.item()])
+    np.testing.assert_allclose(got, net_gold["train228_losses"], rtol=1e-4)
+    np.testing.assert_allclose(parts["final_depth"].detach()[:, :, :4, :4].cpu().numpy(), net_gold["train228_final_depth_corner"], rtol=1e-4, atol=1e-6)
     loss.backward()
     sd = m.state_dict()
     for k in net_gold.files:
@@ -80,26 +79,24 @@ def test_train_step_vs_reference_goldens(dev, net_gold):
     for n in ["d_1.conv1.weight", "d_1.conv1.bias", "weight_layer.f4"]:
         assert params[n].grad is None
     for n in ["weight_layer.d0", "weight_layer.f1", "weight_layer.f2", "weight_layer.f3", "d_1.conv2.bias"]:
-        if np.array_equal(dec, net_gold["train228_decode_c"]):
-            ref = net_gold["train228_grad__" + n]
-            np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+        ref = net_gold["train228_grad__" + n]
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
 def test_eval_forward_226_vs_reference(dev, net_gold):
     m = make_model(dev, train=False)
-    x, _ = filler.synthetic_batch(1, 226, 226, seed=77)
+    x, _ = filler.synthetic_batch(1, 226, 226, seed=SEED["eval226"])
     with torch.no_grad():
         yh, dec, P = m(torch.from_numpy(x).to(dev))
     check_head(dec.cpu().numpy(), P.cpu().numpy(), net_gold["eval226_decode_c"], net_gold["eval226_ord_labels"], net_gold["eval226_logits"])
     np.testing.assert_allclose(stats3(m.debug_buffer("blk3")), net_gold["eval226_tap_d1_dense"], rtol=1e-4, atol=1e-6)
-    if np.array_equal(dec.cpu().numpy(), net_gold["eval226_decode_c"]):
-        for i in range(4):
-            np.testing.assert_allclose(yh[i].cpu().numpy(), net_gold[f"eval226_yhat{i}"], rtol=1e-4, atol=5e-6)
+    for i in range(4):
+        np.testing.assert_allclose(yh[i].cpu().numpy(), net_gold[f"eval226_yhat{i}"], rtol=1e-4, atol=5e-6)
 
 
 def test_rectangular_228x304_head_vs_reference(dev, net_gold):
     m = make_model(dev)
-    x, _ = filler.synthetic_batch(2, 228, 304, seed=1234)
+    x, _ = filler.synthetic_batch(2, 228, 304, seed=SEED["train228x304"])
     with torch.no_grad():
         yh, dec, P = m(torch.from_numpy(x).to(dev))
     assert dec.shape == (2, 1, 8, 10)
@@ -110,10 +107,18 @@ def test_rectangular_228x304_head_vs_reference(dev, net_gold):
     assert [tuple(t.shape) for t in yh] == [(2, 1, 1, 1), (2, 1, 2, 2), (2, 1, 4, 4), (2, 1, 8, 8)]      # documented generalisation
 
 
-def test_gradients_vs_float64_oracle(dev):
+def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gold):
+    """Backward parity, tensor by tensor (491 tensors with a gradient):
+    (a) element-wise: max|g_hip - g_f64| / max|g_f64| <= K_ELEM x the same quantity of the float32 ORACLE for that tensor
+        (+ a float-rounding floor) - each tensor is held to its OWN noise level, nothing is pooled;
+    (b) norms: | ||g_hip|| - N_ref | / N_ref, N_ref = the norm the REFERENCE itself produced for that tensor (fixture
+        train228_grad_norm), bounded by K_NORM x that tensor's own |(||g_f32|| - ||g_f64||)| / ||g_f64|| (+ floor).
+    The reference and the HIP path are two float32 evaluations of one piecewise-linear function: each deviates from the float64
+    value by that tensor's noise, so their mutual distance is bounded by a small multiple of it."""
     from md_rdm_amd import harness
+    K_ELEM, FLOOR_ELEM, K_NORM, FLOOR_NORM = 4.0, 2e-4, 4.0, 5e-4
     B = 2
-    x, y = filler.synthetic_batch(B, 228, 228, seed=1234)
+    x, y = filler.synthetic_batch(B, 228, 228, seed=SEED["train228"])
     m = make_model(dev)
     loss, _ = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
     loss.backward()
@@ -121,19 +126,26 @@ def test_gradients_vs_float64_oracle(dev):
     sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in onet.new_state_dict(filler.state_value).items()}
     r64 = onet.training_step(sd64, torch.from_numpy(x).double(), y)
     assert abs(loss.item() - r64["loss_all"]) < 1e-4 * abs(r64["loss_all"])
-    ours, ref32 = [], []
+    gold_norm = dict(zip([str(n) for n in net_gold["train228_grad_names"]], net_gold["train228_grad_norm"]))
+    checked, report = 0, []
     for n, p in m.named_parameters():
         g64 = r64["grads"].get(n)
         if g64 is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            assert gold_norm[n] < 0, n                                        # the reference has no gradient there either
             continue
+        g = p.grad.cpu().double()
+        g32 = r32["grads"][n].double()
         den = g64.abs().max().item() + 1e-30
-        ours.append((p.grad.cpu().double() - g64).abs().max().item() / den)
-        ref32.append((r32["grads"][n].double() - g64).abs().max().item() / den)
-    ours, ref32 = np.array(ours), np.array(ref32)
-    assert np.median(ours) <= 2.0 * np.median(ref32) + 1e-4, (np.median(ours), np.median(ref32))
-    assert np.percentile(ours, 90) <= 2.0 * np.percentile(ref32, 90) + 1e-3
-    assert ours.max() <= 3.0 * ref32.max() + 1e-2
+        e_hip, e_f32 = (g - g64).abs().max().item() / den, (g32 - g64).abs().max().item() / den
+        n64 = g64.norm().item()
+        en_f32 = abs(g32.norm().item() - n64) / n64
+        en_hip = abs(g.norm().item() - gold_norm[n]) / gold_norm[n]
+        report.append((n, e_hip, e_f32, en_hip, en_f32))
+        checked += 1
+    assert checked == 487 or checked >= 480, checked                           # 491 parameter tensors minus d_1.conv1.* and the empty f4..f7
+    bad = [(n, eh, ef, nh, nf) for n, eh, ef, nh, nf in report if eh > K_ELEM * ef + FLOOR_ELEM or nh > K_NORM * nf + FLOOR_NORM]
+    assert not bad, "per-tensor gradient parity failed for %d tensors, worst: %r" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])
 
 
 def test_direct_gradient_mode_and_fused_adamw(dev):
@@ -158,6 +170,71 @@ def test_direct_gradient_mode_and_fused_adamw(dev):
     for n in ["encoder.conv_e1.weight", "encoder.dense_e2.denselayer1.norm1.bias", "d_1.conv2.bias", "weight_layer.d0"]:
         np.testing.assert_allclose(pb[n].detach().cpu().numpy(), pa[n].detach().cpu().numpy(), rtol=0, atol=2.1e-4)   # first Adam step moves every weight by ~lr
     assert (b._flat[0] - flat0).abs().max().item() > 5e-5
+
+
+def test_fused_adamw_three_steps_vs_torch_and_gradless_params_untouched(dev):
+    """module.py:41 torch.optim.AdamW skips parameters whose .grad is None: d_1.conv1.* (RDM_Net.py:146,156-157) must stay
+    bit-unchanged (no weight decay, no moments); every other tensor must follow torch's AdamW fed the SAME gradients."""
+    from md_rdm_amd import harness
+    x, y = filler.synthetic_batch(2, 228, 228, seed=9)
+    xa, ya = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    a, b = make_model(dev), make_model(dev)
+    b.flatten_parameters()
+    b.direct_grads = True
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    init = {n: p.detach().clone() for n, p in pb.items()}
+    opt = harness.FusedAdamW(b, lr=1e-4)
+    assert len(opt.trainable_ranges()) == 2                      # [conv_e1 .. last dense layer], [d_1.conv2.*]; d_1.conv1.* lies between
+    ref = torch.optim.AdamW([p for p in a.parameters() if p.requires_grad], lr=1e-4)
+    for step in range(3):
+        opt.zero_grad()
+        loss, _ = harness.training_step(b, xa, ya)
+        loss.backward()
+        for n, p in pb.items():                                   # the reference optimiser sees exactly the gradients ours sees
+            pa[n].grad = None if p.grad is None else p.grad.detach().clone()
+        assert pb["d_1.conv1.weight"].grad is None and pb["d_1.conv1.bias"].grad is None
+        opt.step()
+        ref.step()
+    worst = 0.0
+    for n, p in pb.items():
+        if n.startswith("d_1.conv1.") or p.numel() == 0:
+            continue
+        d = (p.detach() - pa[n].detach()).abs().max().item()
+        worst = max(worst, d)
+        assert d <= 2e-8 + 1e-6 * pa[n].detach().abs().max().item(), (n, d)
+        assert (p.detach() - init[n]).abs().max().item() > 1e-5, n     # and it did move
+    for n in ["d_1.conv1.weight", "d_1.conv1.bias"]:
+        assert torch.equal(pb[n].detach(), init[n]), n                # bit-unchanged, as under torch.optim.AdamW
+        assert torch.equal(pa[n].detach(), init[n]), n
+    flat, _, entries = b._flat
+    for k, p, o, n, g in entries:
+        if k.startswith("d_1.conv1."):
+            assert float(opt.m[o:o + n].abs().max()) == 0 and float(opt.v[o:o + n].abs().max()) == 0
+
+
+def test_fused_adamw_leaves_frozen_encoder_bit_identical(dev):
+    """freeze_encoder() (RDM_Net.py:65-67, module.py:38-41): frozen tensors get no gradient, so torch's AdamW never touches them."""
+    from md_rdm_amd import harness
+    x, y = filler.synthetic_batch(2, 228, 228, seed=9)
+    xa, ya = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    m = make_model(dev)
+    m.freeze_encoder()
+    m.flatten_parameters()
+    m.direct_grads = True
+    init = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt = harness.FusedAdamW(m, lr=1e-4)
+    for _ in range(2):
+        opt.zero_grad()
+        loss, _ = harness.training_step(m, xa, ya)
+        loss.backward()
+        opt.step()
+    moved = 0
+    for n, p in m.named_parameters():
+        if n.startswith("encoder.") or n.startswith("d_1.conv1."):
+            assert p.grad is None and torch.equal(p.detach(), init[n]), n
+        elif p.numel():
+            moved += int((p.detach() - init[n]).abs().max().item() > 1e-5)
+    assert moved > 90                                              # the decoder (24 layers x 6 tensors + conv2) and the 4 scalars train
 
 
 def test_full_size_properties_b16_228x304(dev):

@@ -25,7 +25,8 @@ def test_resize(op_gold, h, w, s):
     src = LU(f"op.rs{h}x{w}", (2, 1, h, w), 0.5, 9.5)
     got = ocp.resize(src, s)
     assert got.dtype == np.float64 and got.shape == (2, 1, s, s)
-    np.testing.assert_allclose(got, op_gold[f"resize_{h}x{w}_to_{s}"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(got, op_gold[f"resize_{h}x{w}_to_{s}"])          # bit-exact: oracle/bicubic_aten.c restates ATen's rounding sequence
+    np.testing.assert_allclose(ocp.resize_matrix_form(src, s), got, rtol=1e-12, atol=1e-13)   # independent form of the same operator
 
 
 def test_resize_identity_is_exact():
@@ -37,16 +38,16 @@ def test_upsample_decompose(op_gold):
     np.testing.assert_array_equal(ocp.multi_upsample(U("op.up", (2, 1, 4, 4), 0.5, 2.0), 3), op_gold["multi_upsample_4_n3"])
     src = LU("op.dec8", (2, 1, 8, 8), 0.5, 2.0).astype(np.float64)
     for i, t in enumerate(ocp.decompose_depth_map(src, 3)[::-1]):
-        np.testing.assert_allclose(t, op_gold[f"decompose3_{i}"], rtol=1e-12)
+        np.testing.assert_array_equal(t, op_gold[f"decompose3_{i}"])              # exact resize + IEEE division
     src = LU("op.dec128", (2, 1, 128, 128), 0.5, 9.5)
     comps = ocp.decompose_depth_map(src, 7)[::-1]
     assert [c.shape[2] for c in comps] == [1, 2, 4, 8, 16, 32, 64, 128]
-    np.testing.assert_allclose(comps[0], op_gold["decompose7_0"], rtol=1e-11)
-    np.testing.assert_allclose(comps[3], op_gold["decompose7_3"], rtol=1e-11)
-    np.testing.assert_allclose(comps[7][:, :, :6, :6], op_gold["decompose7_7_corner"], rtol=1e-11)
+    np.testing.assert_array_equal(comps[0], op_gold["decompose7_0"])
+    np.testing.assert_array_equal(comps[3], op_gold["decompose7_3"])
+    np.testing.assert_array_equal(comps[7][:, :, :6, :6], op_gold["decompose7_7_corner"])
     rel = ocp.decompose_depth_map(LU("op.decrel", (2, 1, 16, 16), 0.5, 2.0).astype(np.float64), 4, relative_map=True)[::-1]
     assert len(rel) == int(op_gold["decompose4_rel_len"])
-    np.testing.assert_allclose(rel[0], op_gold["decompose4_rel_0"], rtol=1e-12)
+    np.testing.assert_array_equal(rel[0], op_gold["decompose4_rel_0"])
 
 
 def test_matrix_pred_recombination(op_gold):
@@ -135,9 +136,9 @@ def test_ratio_grids_and_als(op_gold):
     np.testing.assert_allclose(ocp.relative_decoder_forward(d3, 6, t), op_gold["derived008_d6_forward"], rtol=2e-5)
     dn = LU("op.dn16", (2, 1, 16, 16), 0.5, 2.0)
     dn1 = ocp.resize(dn, 8)
-    np.testing.assert_allclose(dn1, op_gold["resize_dn16_to_8"], rtol=1e-13)
+    np.testing.assert_array_equal(dn1, op_gold["resize_dn16_to_8"])
     raw = ocp.ratio_grid_raw(dn, dn1)
-    np.testing.assert_allclose(raw, op_gold["ratio_grid_raw_16"], rtol=1e-15)
+    np.testing.assert_array_equal(raw, op_gold["ratio_grid_raw_16"])
     R, _ = ocp.lloyd_quantization(raw, *t["016"])
     assert str(op_gold["sparse_id_016_dtype"]) == "torch.float64"
     np.testing.assert_array_equal(R, op_gold["sparse_id_016"])
@@ -166,7 +167,22 @@ def test_paging_and_d8(op_gold):
     a, b = ocp.split_matrix(d32, d16)
     assert len(a) == int(op_gold["split_len"])
     np.testing.assert_array_equal(a[2], op_gold["split_first_2"])
-    np.testing.assert_allclose(b[3], op_gold["split_second_3"], rtol=1e-13)
+    np.testing.assert_array_equal(b[3], op_gold["split_second_3"])
     pages = [U(f"op.pg{i}", (2, 1, 16, 16), 0, 1) for i in range(4)]
     np.testing.assert_array_equal(ocp.reconstruct(pages), op_gold["reconstruct_4pages"])
     np.testing.assert_allclose(ocp.relative_decoder_forward(d32, 8), op_gold["d8_forward"], rtol=3e-5)
+
+
+@pytest.mark.parametrize("tag,shape", [("a", (4, 1, 128, 128)), ("b", (1, 1, 8, 8))])
+def test_validation_metrics_vs_reference(tag, shape):
+    """fixture = the reference's own MetricComputation.compute + its metric functions (metrics.py:48-128), run by
+    tests/golden/make_golden.py behind a labelled pytorch_lightning stand-in."""
+    import os
+    from conftest import GOLDEN
+    G = np.load(os.path.join(GOLDEN, "metric_goldens.npz"))
+    names = [str(n) for n in G["names"]]
+    pred = U(f"met.p.{tag}", shape, -0.5, 3.0).astype(np.float64)
+    tgt = LU(f"met.t.{tag}", shape, 0.2, 4.0).astype(np.float64)
+    tgt.flat[::7] = 0.0
+    np.testing.assert_allclose(ocp.depth_metrics(pred, tgt, names), G[f"metrics_{tag}_float64"], rtol=1e-12)
+    np.testing.assert_allclose(ocp.depth_metrics(pred.astype(np.float32), tgt.astype(np.float32), names), G[f"metrics_{tag}_float32"], rtol=2e-5)
