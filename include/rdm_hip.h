@@ -100,6 +100,50 @@ int rdm_unpack_conv_weight(const float* w_packed, float* w_oihw, int32_t out_c, 
                            int32_t out_c_padded, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BatchNorm / pooling pieces of the conv stack as operators (the plan below enqueues the same kernels).
+ * Reference call sites: torchvision _DenseLayer / _Transition BatchNorm2d + ReLU reached from
+ * network/RDM_Net.py:144,526-531 (third party, restated in tests/golden/make_golden.py), max_e1 :525,
+ * pad_br + trans_e* (ZeroPad2d((0,1,0,1)) -> BatchNorm -> ReLU -> conv -> AvgPool2d(2)) :527,529,531-532.
+ * All tensors NHWC float32 with a pixel stride `ld` >= channels; channels a multiple of 4; 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+/* sum[c] += sum_m x[m][c], sumsq[c] += sum_m x[m][c]^2 over `rows` pixels (f64, pre-zeroed by the caller; sumsq may be NULL) */
+int rdm_bn_stats(const float* x, int32_t ld, int64_t rows, int32_t channels, double* sum, double* sumsq, rdm_stream_t stream);
+/* nn.BatchNorm2d bookkeeping from the sums: training != 0 -> batch mean / biased variance over `count` elements per channel,
+ * running_mean / running_var (momentum 0.1, unbiased variance) and *num_batches_tracked updated; training == 0 -> running
+ * statistics.  Outputs: scale = gamma * rstd and shift = beta - mean * scale (what a conv prologue applies), mean and
+ * rstd = 1/sqrt(var + 1e-5) (what backward needs). */
+int rdm_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    int32_t channels, int32_t training, rdm_stream_t stream);
+/* ReLU gate + the two BatchNorm-backward reductions: dz[m][c] = dy[m][c] * [x*scale+shift > 0] (in place),
+ * sum_dz[c] += sum_m dz, sum_dz_x[c] += sum_m dz * x (f64, pre-zeroed) */
+int rdm_bn_bwd_reduce(float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const float* scale, const float* shift, int64_t rows,
+                      int32_t channels, double* sum_dz, double* sum_dz_x, rdm_stream_t stream);
+/* BatchNorm backward from the reductions: dx (=|+= when accumulate) gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) in training,
+ * gamma*rstd*dz in eval; dgamma[c] = sum dz*xhat, dbeta[c] = sum dz (either may be NULL). */
+int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const double* sum_dz,
+               const double* sum_dz_x, double count, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
+               float* dbeta, int64_t rows, int32_t channels, int32_t accumulate, int32_t training, rdm_stream_t stream);
+/* nn.MaxPool2d(3, stride 2, padding 1): x (B,H,W,C) contiguous -> y (B,Ho,Wo,C) with pixel stride y_ld; argmax (B,Ho,Wo,C) uint8 = winning
+ * tap r*3+s (first maximum in scan order, as ATen).  Backward is the gather form: dx (B,H,W,C) contiguous, every element written. */
+int rdm_maxpool3s2_fwd(const float* x, float* y, int32_t y_ld, uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t channels,
+                       rdm_stream_t stream);
+int rdm_maxpool3s2_bwd(const float* dy, int32_t dy_ld, const uint8_t* argmax, float* dx, int32_t batch, int32_t h, int32_t w, int32_t channels,
+                       rdm_stream_t stream);
+/* Transition front end: pooled (B,ceil(H/2),ceil(W/2),C) contiguous = AvgPool2d(2)(relu(pad_br(x) * scale + shift)) - the zero row /
+ * column of pad_br is a BatchNorm INPUT (it contributes relu(shift)), and (scale, shift) must come from statistics over the padded
+ * extent: rdm_bn_stats over the real pixels with count = B*(H+1)*(W+1).  The 1x1 conv of the transition is linear and is applied
+ * to the pooled tensor (rdm_conv2d_fwd). */
+int rdm_padavgpool2_fwd(const float* x, int32_t x_ld, const float* scale, const float* shift, float* pooled, int32_t batch, int32_t h,
+                        int32_t w, int32_t channels, rdm_stream_t stream);
+/* its backward incl. the BatchNorm: dx (B,H,W,C; pixel stride dx_ld; every element written) and dgamma / dbeta from dpooled.
+ * workspace: rdm_padavgpool2_bwd_workspace_bytes(channels) bytes, 256-byte aligned (reductions + per-channel coefficients). */
+size_t rdm_padavgpool2_bwd_workspace_bytes(int32_t channels);
+int rdm_padavgpool2_bwd(const float* dpooled, const float* x, int32_t x_ld, const float* scale, const float* shift, const float* gamma,
+                        const float* save_mean, const float* save_rstd, float* dx, int32_t dx_ld, float* dgamma, float* dbeta, int32_t batch,
+                        int32_t h, int32_t w, int32_t channels, int32_t training, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * The whole convolutional stack of DepthEstimationNet as one native plan:
  *   network/RDM_Net.py:73-94 (encoder) + :150-159 (Decoder d_1 up to conv2), forward and backward,
  *   train-mode (batch statistics + running-stat update) or eval-mode BatchNorm.
@@ -123,6 +167,21 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */
 int rdm_net_forward(rdm_net* net, const float* x_nchw, void* const* tensors, void* workspace, size_t workspace_bytes,
                     float* logits_nchw, int32_t training, rdm_stream_t stream);
+
+/* Reduced-precision forward (BASELINE config 2, "batch=8 forward-only bf16"; the reference's default precision is mixed,
+ * train.py:11,57-58): bf16 weights and activations in HBM, v_mfma_f32_16x16x32_bf16 with f32 accumulation, eval-mode BatchNorm
+ * (running statistics) applied in f32 inside the conv staging, f32 bias and f32 logits.  Inference only: no statistics update, no
+ * saved activations, no backward.
+ *   rdm_net_bf16_prepare      converts every conv weight to bf16 (3x3: [tap][out][in]) and folds every BatchNorm to (scale, shift)
+ *                             into `wbuf` (rdm_net_bf16_weight_bytes, 256-byte aligned, caller-owned); call again after a weight update.
+ *   rdm_net_forward_bf16      x (B,3,H,W) f32 NCHW -> logits (B,180,h,w) f32 NCHW; `tensors` supplies the two f32 bias vectors.
+ *   rdm_net_bf16_forward_bytes  algorithmic HBM bytes of one such forward (each activation written once and read once per consumer) */
+size_t rdm_net_bf16_weight_bytes(const rdm_net* net);
+size_t rdm_net_bf16_workspace_bytes(const rdm_net* net);
+double rdm_net_bf16_forward_bytes(const rdm_net* net);
+int rdm_net_bf16_prepare(rdm_net* net, void* const* tensors, void* wbuf, size_t wbuf_bytes, rdm_stream_t stream);
+int rdm_net_forward_bf16(rdm_net* net, const float* x_nchw, void* const* tensors, const void* wbuf, size_t wbuf_bytes, void* workspace,
+                         size_t workspace_bytes, float* logits_nchw, rdm_stream_t stream);
 
 /* Backward in up to 4 segments so the caller can start reducing a segment's gradients (RCCL)
  * while the next one computes: 0 = decoder d_1, 1 = dense_e4+trans_e4, 2 = dense_e3+trans_e3,

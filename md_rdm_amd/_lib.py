@@ -35,6 +35,15 @@ _SIGNATURES = {
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_bn_stats": (C.c_int, [vp, i32, i64, i32, vp, vp, vp]),
+    "rdm_bn_finalize": (C.c_int, [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "rdm_bn_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, vp, i64, i32, vp, vp, vp]),
+    "rdm_bn_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, vp, f64, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "rdm_maxpool3s2_fwd": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "rdm_maxpool3s2_bwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_padavgpool2_fwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_padavgpool2_bwd_workspace_bytes": (sz, [i32]),
+    "rdm_padavgpool2_bwd": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "rdm_net_num_tensors": (C.c_int, []),
     "rdm_net_tensor_name": (C.c_char_p, [i32]),
     "rdm_net_tensor_numel": (i64, [i32]),
@@ -44,6 +53,11 @@ _SIGNATURES = {
     "rdm_net_workspace_bytes": (sz, [vp]),
     "rdm_net_output_hw": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "rdm_net_forward": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, i32, vp]),
+    "rdm_net_bf16_weight_bytes": (sz, [vp]),
+    "rdm_net_bf16_workspace_bytes": (sz, [vp]),
+    "rdm_net_bf16_forward_bytes": (f64, [vp]),
+    "rdm_net_bf16_prepare": (C.c_int, [vp, C.POINTER(vp), vp, sz, vp]),
+    "rdm_net_forward_bf16": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, sz, vp, vp]),
     "rdm_net_backward": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, sz, i32, i32, vp]),
     "rdm_net_segment_range": (C.c_int, [i32, C.POINTER(i32), C.POINTER(i32)]),
     "rdm_net_buffer": (C.c_int, [vp, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]),

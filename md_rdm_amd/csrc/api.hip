@@ -121,6 +121,105 @@ int rdm_unpack_conv_weight(const float* wp, float* w, int32_t out_c, int32_t in_
   return launch_unpack_w(wp, w, out_c, in_c, kh * kw, out_c_padded, stream);
 }
 
+static int check_nhwc(const void* p, int ld, int channels, const char* what) {
+  RDM_CHECK_ARG(p != nullptr, "%s: NULL tensor", what);
+  RDM_CHECK_ARG(channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0, "%s: channels (%d) and pixel stride (%d) must be multiples of 4, stride >= channels", what, channels, ld);
+  RDM_CHECK_ARG(((uintptr_t)p & 15) == 0, "%s: tensor must be 16-byte aligned", what);
+  return 0;
+}
+
+int rdm_bn_stats(const float* x, int32_t ld, int64_t rows, int32_t channels, double* sum, double* sumsq, rdm_stream_t stream) {
+  if (int rc = check_nhwc(x, ld, channels, "bn_stats")) return rc;
+  RDM_CHECK_ARG(sum != nullptr && rows > 0 && rows < (1L << 31), "bn_stats: bad argument");
+  return launch_colstats(x, ld, (int)rows, channels, sum, sumsq, stream);
+}
+
+int rdm_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    int32_t channels, int32_t training, rdm_stream_t stream) {
+  RDM_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && save_mean && save_rstd && channels > 0, "bn_finalize: NULL argument");
+  RDM_CHECK_ARG(!training || (sum && sumsq && count >= 1), "bn_finalize: training mode needs the sums and a positive count");
+  return launch_bn_finalize(sum, sumsq, count, gamma, beta, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), scale, shift,
+                            save_mean, save_rstd, channels, training, stream);
+}
+
+int rdm_bn_bwd_reduce(float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const float* scale, const float* shift, int64_t rows,
+                      int32_t channels, double* sum_dz, double* sum_dz_x, rdm_stream_t stream) {
+  if (int rc = check_nhwc(dz, dz_ld, channels, "bn_bwd_reduce(dz)")) return rc;
+  if (int rc = check_nhwc(x, x_ld, channels, "bn_bwd_reduce(x)")) return rc;
+  RDM_CHECK_ARG(scale && shift && sum_dz && sum_dz_x && rows > 0 && rows < (1L << 31), "bn_bwd_reduce: bad argument");
+  RDM_CHECK_ARG((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "bn_bwd_reduce: scale / shift must be 16-byte aligned");
+  return launch_mask_stats(dz, dz_ld, x, x_ld, scale, shift, (int)rows, channels, sum_dz, sum_dz_x, stream);
+}
+
+int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const double* sum_dz,
+               const double* sum_dz_x, double count, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
+               float* dbeta, int64_t rows, int32_t channels, int32_t accumulate, int32_t training, rdm_stream_t stream) {
+  if (int rc = check_nhwc(dx, dx_ld, channels, "bn_bwd(dx)")) return rc;
+  if (int rc = check_nhwc(dz, dz_ld, channels, "bn_bwd(dz)")) return rc;
+  if (int rc = check_nhwc(x, x_ld, channels, "bn_bwd(x)")) return rc;
+  RDM_CHECK_ARG(sum_dz && sum_dz_x && gamma && save_mean && save_rstd && rows > 0 && rows < (1L << 31) && count >= 1, "bn_bwd: bad argument");
+  return launch_bn_bwd_apply(dx, dx_ld, dz, dz_ld, x, x_ld, sum_dz, sum_dz_x, count, gamma, save_mean, save_rstd, dgamma, dbeta, (int)rows, channels,
+                             accumulate != 0, training, stream);
+}
+
+int rdm_maxpool3s2_fwd(const float* x, float* y, int32_t y_ld, uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t channels,
+                       rdm_stream_t stream) {
+  if (int rc = check_nhwc(x, channels, channels, "maxpool3s2_fwd(x)")) return rc;
+  if (int rc = check_nhwc(y, y_ld, channels, "maxpool3s2_fwd(y)")) return rc;
+  RDM_CHECK_ARG(argmax && ((uintptr_t)argmax & 3) == 0 && batch > 0 && h > 0 && w > 0, "maxpool3s2_fwd: bad argument");
+  return launch_maxpool3s2(x, y, y_ld, argmax, batch, h, w, channels, stream);
+}
+
+int rdm_maxpool3s2_bwd(const float* dy, int32_t dy_ld, const uint8_t* argmax, float* dx, int32_t batch, int32_t h, int32_t w, int32_t channels,
+                       rdm_stream_t stream) {
+  if (int rc = check_nhwc(dy, dy_ld, channels, "maxpool3s2_bwd(dy)")) return rc;
+  if (int rc = check_nhwc(dx, channels, channels, "maxpool3s2_bwd(dx)")) return rc;
+  RDM_CHECK_ARG(argmax && ((uintptr_t)argmax & 3) == 0 && batch > 0 && h > 0 && w > 0, "maxpool3s2_bwd: bad argument");
+  return launch_maxpool3s2_bwd(dy, dy_ld, argmax, dx, batch, h, w, channels, stream);
+}
+
+int rdm_padavgpool2_fwd(const float* x, int32_t x_ld, const float* scale, const float* shift, float* pooled, int32_t batch, int32_t h,
+                        int32_t w, int32_t channels, rdm_stream_t stream) {
+  if (int rc = check_nhwc(x, x_ld, channels, "padavgpool2_fwd(x)")) return rc;
+  if (int rc = check_nhwc(pooled, channels, channels, "padavgpool2_fwd(pooled)")) return rc;
+  RDM_CHECK_ARG(scale && shift && (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0 && batch > 0 && h > 0 && w > 0, "padavgpool2_fwd: bad argument");
+  return launch_trans_pool(x, x_ld, scale, shift, pooled, batch, h, w, channels, stream);
+}
+
+static size_t pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+size_t rdm_padavgpool2_bwd_workspace_bytes(int32_t channels) {
+  return channels > 0 ? pad256(2 * (size_t)channels * sizeof(double)) + 3 * pad256((size_t)channels * sizeof(float)) : 0;
+}
+
+int rdm_padavgpool2_bwd(const float* dpooled, const float* x, int32_t x_ld, const float* scale, const float* shift, const float* gamma,
+                        const float* save_mean, const float* save_rstd, float* dx, int32_t dx_ld, float* dgamma, float* dbeta, int32_t batch,
+                        int32_t h, int32_t w, int32_t channels, int32_t training, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  if (int rc = check_nhwc(dpooled, channels, channels, "padavgpool2_bwd(dpooled)")) return rc;
+  if (int rc = check_nhwc(x, x_ld, channels, "padavgpool2_bwd(x)")) return rc;
+  if (int rc = check_nhwc(dx, dx_ld, channels, "padavgpool2_bwd(dx)")) return rc;
+  RDM_CHECK_ARG(scale && shift && gamma && save_mean && save_rstd && batch > 0 && h > 0 && w > 0, "padavgpool2_bwd: bad argument");
+  RDM_CHECK_ARG((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "padavgpool2_bwd: scale / shift must be 16-byte aligned");
+  RDM_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "padavgpool2_bwd: workspace must be 256-byte aligned");
+  if (workspace_bytes < rdm_padavgpool2_bwd_workspace_bytes(channels)) {
+    set_error("padavgpool2_bwd: workspace too small: %zu < %zu", workspace_bytes, rdm_padavgpool2_bwd_workspace_bytes(channels));
+    return RDM_ERR_WORKSPACE_TOO_SMALL;
+  }
+  char* ws = static_cast<char*>(workspace);
+  double* s0 = reinterpret_cast<double*>(ws);
+  double* s1 = s0 + channels;
+  const size_t coff = pad256(2 * (size_t)channels * sizeof(double)), cstep = pad256((size_t)channels * sizeof(float));
+  float* cA = reinterpret_cast<float*>(ws + coff);
+  float* cB = reinterpret_cast<float*>(ws + coff + cstep);
+  float* cC = reinterpret_cast<float*>(ws + coff + 2 * cstep);
+  RDM_HIP_OK(hipMemsetAsync(s0, 0, 2 * (size_t)channels * sizeof(double), stream));
+  int rc = launch_trans_pool_bwd_reduce(dpooled, x, x_ld, scale, shift, batch, h, w, channels, s0, s1, stream);
+  if (rc) return rc;
+  const double count = (double)batch * (h + 1) * (w + 1);
+  if ((rc = launch_bn_bwd_coeffs(s0, s1, count, gamma, save_mean, save_rstd, cA, cB, cC, dgamma, dbeta, channels, training, stream))) return rc;
+  return launch_trans_pool_bwd_apply(dpooled, x, x_ld, scale, shift, cA, cB, cC, dx, dx_ld, batch, h, w, channels, stream);
+}
+
 int rdm_adamw_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float grad_scale, rdm_stream_t stream) {
   RDM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adamw_fused: bad argument");

@@ -1,0 +1,32 @@
+// internal declarations of the bf16 forward kernels (bf16.hip); not part of the C ABI
+#pragma once
+#include <hip/hip_runtime.h>
+namespace rdm {
+
+struct GemmBf16Args {        // out[m][n] = bias[n] + sum_k f(X[m][k]) * W[n][k],  f = relu(x*scale[k]+shift[k]) when scale != NULL
+  const void* X; int ldx; int K;           // bf16 activations [M][ldx] (k-contiguous), contracted extent (multiple of 8)
+  const float* scale; const float* shift;  // optional eval-mode BatchNorm affine + ReLU over k
+  const void* W; int ldw;                  // bf16 weights [N][ldw]
+  void* out; int ldc; int M, N;            // bf16 (or f32) [M][ldc]
+  const float* bias;                       // optional f32[N]
+  unsigned x_bytes, w_bytes, p_bytes;      // set by the launcher (buffer descriptors)
+};
+
+struct Conv3Bf16Args {       // out[m][n] = sum_{tap,c} relu(Y[pix(m,tap)][c]*scale[c]+shift[c]) * Wt[tap][n][c], zero padding, n < 48
+  const void* Y; int ldy; int C;           // bf16 [M][ldy], C multiple of 8
+  const float* scale; const float* shift;
+  const void* Wt; long wtap; int ldw;      // bf16 [9][48][ldw]
+  unsigned short* out; int ldc;            // bf16 [M][ldc] (a 48-channel slice of the block buffer)
+  int B, H, W, M;
+  unsigned y_bytes, w_bytes, p_bytes;
+};
+
+int launch_gemm_bf16(const GemmBf16Args& a, bool out_f32, hipStream_t s);
+int launch_conv3x3_bf16(const Conv3Bf16Args& a, hipStream_t s);
+int launch_f32_to_bf16_rows(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int cols_pad, hipStream_t s);
+int launch_pack_w_bf16(const float* w_oihw, void* w_packed, int O, int I, int T, hipStream_t s);
+int launch_im2col_stem_bf16(const float* x, void* patches, int B, int H, int W, hipStream_t s);
+int launch_maxpool3s2_bf16(const void* X, void* Y, int ldy, int B, int H, int W, int C, hipStream_t s);
+int launch_trans_pool_bf16(const void* X, int ldx, const float* sc, const float* sh, void* P, int B, int H, int W, int C, hipStream_t s);
+
+}  // namespace rdm

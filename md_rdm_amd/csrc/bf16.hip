@@ -1,0 +1,530 @@
+// Reduced-precision FORWARD of the conv stack (BASELINE config 2: "NYU-v2 batch=8 forward-only bf16").
+//
+// The reference's default is mixed precision (train.py:11 `--precision 16`, :57-58 AMP O2: fp16 convs, fp32 BatchNorm);
+// its inference pass is network/module.py:49-56 -> network/RDM_Net.py:70-103.  Here the same pass runs with
+//   * bf16 activations and weights in HBM (half the bytes of every block buffer / bottleneck tensor),
+//   * v_mfma_f32_16x16x32_bf16 with f32 accumulation (16x the f32-MFMA rate),
+//   * f32 BatchNorm affines applied in the conv staging registers (eval mode: running statistics, folded once per weight
+//     update by rdm_net_bf16_prepare), f32 bias, f32 logits; the f64 DORN tail is unchanged.
+// Two kernels carry > 99 % of the work:
+//   gemm_bf16_kernel     1x1 convs (and the im2col'd stem): C[m][n] = sum_k f(X[m][k]) * W[n][k], both operands k-contiguous
+//   conv3x3_bf16_kernel  the 3x3 / pad 1 / 48-output conv of every dense layer on an LDS halo tile (each activation is
+//                        staged and normalised ONCE per 9 taps)
+// Operand roles are swapped w.r.t. the f32 kernels: the WEIGHT fragment is the MFMA "A" operand and the ACTIVATION fragment
+// the "B" operand, so a lane's 4 accumulator registers are 4 consecutive output CHANNELS of one pixel: the bf16 result is
+// written as one 8-byte store per lane (32 contiguous bytes per pixel and n-tile) instead of 2-byte scattered stores.
+// LDS images are [row][k] with 16-byte chunks XOR-swizzled so that every ds_read_b128 of a fragment is bank-conflict free
+// for the 16-lane groups the hardware forms (MI355X_MICROARCH.md, LDS): 128-byte rows: chunk ^= (row >> 1) & 7;
+// 64-byte rows read at arbitrary row offsets (halo taps): chunk ^= ((row >> 2) & 1) << 1   (both checked exhaustively).
+#include <algorithm>
+#include <vector>
+
+#include "rdm_common.h"
+#include "elementwise.h"
+#include "bf16.h"
+
+namespace rdm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 bld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 bldf(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const bf16x2 r = {(__bf16)a, (__bf16)b};                  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned bnrelu2(unsigned u, float s0, float s1, float t0, float t1) {
+  return pack2(fmaxf(fmaf(bf_lo(u), s0, t0), 0.f), fmaxf(fmaf(bf_hi(u), s1, t1), 0.f));
+}
+// relu(x * scale + shift) on 8 packed bf16 (channels k .. k+7), f32 arithmetic, one rounding back to bf16
+__device__ __forceinline__ uint4 bnrelu8(uint4 v, float4 sa, float4 sb, float4 ta, float4 tb) {
+  v.x = bnrelu2(v.x, sa.x, sa.y, ta.x, ta.y);
+  v.y = bnrelu2(v.y, sa.z, sa.w, ta.z, ta.w);
+  v.z = bnrelu2(v.z, sb.x, sb.y, tb.x, tb.y);
+  v.w = bnrelu2(v.w, sb.z, sb.w, tb.z, tb.w);
+  return v;
+}
+
+__device__ __forceinline__ void xcd_order(int& bx, int& by) {      // see igemm.hip xcd_block_order
+  const unsigned gx = gridDim.x, total = gx * gridDim.y;
+  const unsigned L = blockIdx.x + gx * blockIdx.y;
+  const unsigned x = L & 7u, seq = L >> 3, q = total >> 3, r = total & 7u;
+  const unsigned Lp = x * q + (x < r ? x : r) + seq;
+  bx = (int)(Lp % gx); by = (int)(Lp / gx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: out[m][n] = bias[n] + sum_k f(X[m][k]) * W[n][k]      f = relu(x*scale[k]+shift[k]) or identity
+// Block = 4 wave64s (WM x WN), wave tile (MT*16 pixels) x (NT*16 channels), K walked in 64-deep steps (2 MFMA k-steps).
+// global -> registers (next step's loads in flight under this step's MFMAs) -> BN-ReLU -> swizzled LDS, 2 buffers, 1 barrier / step.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
+  constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN, BK = 64;
+  constexpr int XL = (BM + 31) / 32, WL = (BN + 31) / 32;          // 16-byte chunks per thread and step
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (BM + BN) * BK];
+  unsigned short* const Xs0 = lds;
+  unsigned short* const Ws0 = lds + 2 * BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wrow = (wave / WN) * MT * 16, wcol = (wave % WN) * NT * 16;
+  int bx, by;
+  xcd_order(bx, by);
+  const int n0 = bx * BN, m0 = by * BM;
+  const __amdgpu_buffer_rsrc_t srdX = srd(p.X, p.x_bytes), srdW = srd(p.W, p.w_bytes);
+  const __amdgpu_buffer_rsrc_t srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
+  const bool bnrelu = p.scale != nullptr;
+
+  const int ch = tid & 7, r0 = tid >> 3;                              // this thread's chunk column and first row
+  unsigned xoff[XL], woff[WL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int r = r0 + 32 * i, m = m0 + r;
+    xoff[i] = (r < BM && m < p.M) ? (unsigned)m * (unsigned)(p.ldx * 2) + (unsigned)(ch * 16) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    const int r = r0 + 32 * i, n = n0 + r;
+    woff[i] = (r < BN && n < p.N) ? (unsigned)n * (unsigned)(p.ldw * 2) + (unsigned)(ch * 16) : OOB;
+  }
+  uint4 rx[XL], rw[WL];
+  float4 sa, sb, ta, tb;
+  auto load_step = [&](int kt) {
+    const int k0 = kt * BK + ch * 8;
+    const bool kok = k0 < p.K;                                        // K is a multiple of 8: a chunk is all in or all out
+    const unsigned kb = (unsigned)(kt * BK * 2);
+#pragma unroll
+    for (int i = 0; i < XL; ++i) rx[i] = bld(srdX, (kok && xoff[i] != OOB) ? xoff[i] + kb : OOB);
+#pragma unroll
+    for (int i = 0; i < WL; ++i) rw[i] = bld(srdW, (kok && woff[i] != OOB) ? woff[i] + kb : OOB);
+    if (bnrelu) {
+      const unsigned po = kok ? (unsigned)(k0 * 4) : OOB;
+      sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
+      ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned short* Xs = Xs0 + buf * BM * BK;
+    unsigned short* Ws = Ws0 + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int r = r0 + 32 * i;
+      if (r < BM) {
+        uint4 v = rx[i];
+        if (bnrelu) v = bnrelu8(v, sa, sb, ta, tb);
+        *reinterpret_cast<uint4*>(Xs + r * BK + ((ch ^ ((r >> 1) & 7)) << 3)) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int r = r0 + 32 * i;
+      if (r < BN) *reinterpret_cast<uint4*>(Ws + r * BK + ((ch ^ ((r >> 1) & 7)) << 3)) = rw[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int sw = (l16 >> 1) & 7;                                      // tile row bases are multiples of 16
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_step(kt + 1);
+    const unsigned short* Xs = Xs0 + buf * BM * BK;
+    const unsigned short* Ws = Ws0 + buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int co = ((ks * 4 + g) ^ sw) << 3;
+      bf16x8 wf[NT], xf[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Ws + (wcol + j * 16 + l16) * BK + co);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(Xs + (wrow + i * 16 + l16) * BK + co);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // D[row = channel 4g+r of the n-tile][col = pixel l16 of the m-tile]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wcol + j * 16 + g * 4;
+    if (n >= p.N) continue;                                            // N is a multiple of 4
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wrow + i * 16 + l16;
+      if (m >= p.M) continue;
+      const float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      if (OUT_F32) {
+        *reinterpret_cast<float4*>(static_cast<float*>(p.out) + (long)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
+      } else {
+        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + (long)m * p.ldc + n) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 / 48 outputs on an LDS halo tile.  A block owns BM = MT*64 consecutive output pixels (linear NHWC
+// index).  Per 32-channel slab: ONE halo run of BM + 2(W+1) pixels (BN-ReLU applied once per element) and the 9 x 48 x 32
+// weight slab are staged; the 9 taps read their activation fragments from the run at pixel offset r*W + q, border / batch
+// wrap-around is undone with a 9-bit validity mask per lane row.  The next slab's global loads are in flight under the
+// 9 x 3 x MT MFMAs of this one (register prefetch), 2 barriers per slab.
+// Dynamic LDS: [halo pixels][32] bf16 + [9*48][32] bf16.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int HL>      // HL >= ceil(halo pixels * 4 / 256): 16-byte halo chunks per thread and slab
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
+  constexpr int BM = MT * 64, NT = 3, CS = 32, WLN = 7;              // 9*48*4 = 1728 weight chunks / 256 threads = 6.75
+  extern __shared__ __attribute__((aligned(16))) unsigned short dyn[];
+  const int W = p.W, H = p.H;
+  const int halo = BM + 2 * (W + 1);
+  unsigned short* const Ah = dyn;
+  unsigned short* const Wl = dyn + (size_t)((halo + 7) & ~7) * CS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wrow = wave * MT * 16;
+  const int m0 = blockIdx.x * BM;
+  const __amdgpu_buffer_rsrc_t srdY = srd(p.Y, p.y_bytes), srdW = srd(p.Wt, p.w_bytes);
+  const __amdgpu_buffer_rsrc_t srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
+
+  unsigned vmask[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wrow + i * 16 + l16;
+    unsigned v = 0;
+    if (m < p.M) {
+      const int hw = H * W, rem = m - (m / hw) * hw;
+      const int oy = rem / W, ox = rem - oy * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(oy + t / 3 - 1) < (unsigned)H && (unsigned)(ox + t % 3 - 1) < (unsigned)W) v |= 1u << t;
+    }
+    vmask[i] = v;
+  }
+  const int ch = tid & 3;                                             // chunk (8 channels) of the 32-channel slab, same for all of a thread's loads
+  unsigned hoff[HL];
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const int hp = (tid + 256 * i) >> 2;
+    const long pix = (long)m0 - (W + 1) + hp;
+    hoff[i] = (hp < halo && pix >= 0 && pix < (long)p.M) ? (unsigned)pix * (unsigned)(p.ldy * 2) + (unsigned)(ch * 16) : OOB;
+  }
+  unsigned woff[WLN];
+#pragma unroll
+  for (int i = 0; i < WLN; ++i) {
+    const int row = (tid + 256 * i) >> 2;                             // tap*48 + n
+    woff[i] = row < 9 * 48 ? (unsigned)(row / 48) * (unsigned)(p.wtap * 2) + (unsigned)(row % 48) * (unsigned)(p.ldw * 2) + (unsigned)(ch * 16) : OOB;
+  }
+  uint4 rh[HL], rw[WLN];
+  float4 sa, sb, ta, tb;
+  auto load_slab = [&](int cs) {
+    const unsigned cb = (unsigned)(cs * CS * 2);
+    // bottleneck widths are 48 * odd: the last slab holds 16 channels.  Chunks past C are forced to zero on BOTH operands (the
+    // activation row continues with the next pixel there) and their affine to 0, so relu(0 * 0 + 0) * 0 contributes nothing.
+    const bool kok = cs * CS + ch * 8 < p.C;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) rh[i] = bld(srdY, (kok && hoff[i] != OOB) ? hoff[i] + cb : OOB);
+#pragma unroll
+    for (int i = 0; i < WLN; ++i) rw[i] = bld(srdW, (kok && woff[i] != OOB) ? woff[i] + cb : OOB);
+    const unsigned po = kok ? (unsigned)((cs * CS + ch * 8) * 4) : OOB;
+    sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
+    ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int hp = (tid + 256 * i) >> 2;
+      if (hp < halo) *reinterpret_cast<uint4*>(Ah + hp * CS + ((ch ^ (((hp >> 2) & 1) << 1)) << 3)) = bnrelu8(rh[i], sa, sb, ta, tb);
+    }
+#pragma unroll
+    for (int i = 0; i < WLN; ++i) {
+      const int row = (tid + 256 * i) >> 2;
+      if (row < 9 * 48) *reinterpret_cast<uint4*>(Wl + row * CS + ((ch ^ (((row >> 2) & 1) << 1)) << 3)) = rw[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ncs = (p.C + CS - 1) / CS;
+  load_slab(0);
+  store_slab();
+  __syncthreads();
+  const int wsw = ((l16 >> 2) & 1) << 1;                              // weight rows of an n-tile start at a multiple of 16
+  for (int cs = 0; cs < ncs; ++cs) {
+    const bool more = cs + 1 < ncs;
+    if (more) load_slab(cs + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int off = wrow + l16 + (tap / 3) * W + (tap % 3);         // halo[0] is pixel m0 - (W+1)
+      bf16x8 wf[NT], xf[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wl + (tap * 48 + j * 16 + l16) * CS + ((g ^ wsw) << 3));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int hp = off + i * 16;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ah + hp * CS + ((g ^ (((hp >> 2) & 1) << 1)) << 3));
+        const uint4 u = __builtin_bit_cast(uint4, v);
+        const unsigned keep = 0u - ((vmask[i] >> tap) & 1u);
+        xf[i] = __builtin_bit_cast(bf16x8, make_uint4(u.x & keep, u.y & keep, u.z & keep, u.w & keep));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                                  // every wave is past its last read of this slab
+    if (more) { store_slab(); __syncthreads(); }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 16 + g * 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wrow + i * 16 + l16;
+      if (m < p.M)
+        *reinterpret_cast<uint2*>(p.out + (long)m * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helper kernels (HBM bound)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_f32_to_bf16_rows(const float* __restrict__ src, int lds_, unsigned short* __restrict__ dst, int ldd, long rows, int cols, int cols_pad) {
+  const long total = rows * cols_pad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols_pad; const int c = (int)(i - r * cols_pad);
+    const float v = c < cols ? src[r * lds_ + c] : 0.f;
+    dst[r * ldd + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  }
+}
+// [O][I][T] (PyTorch OIHW, T = kh*kw) -> [T][O][I] bf16
+__global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ w, unsigned short* __restrict__ wp, int O, int I, int T) {
+  const long total = (long)T * O * I;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % I); const long t = i / I;
+    const int o = (int)(t % O), tap = (int)(t / O);
+    wp[i] = __builtin_bit_cast(unsigned short, (__bf16)w[((long)o * I + c) * T + tap]);
+  }
+}
+// im2col of the 7x7/s2/p3 stem (RDM_Net.py:524): patches[m][k], k = c*49 + r*7 + s, zero for k >= 147, row length 160, bf16
+__global__ __launch_bounds__(256) void k_im2col_stem_bf16(const float* __restrict__ x, unsigned short* __restrict__ patches, int B, int H, int W, int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * 80;                          // two k per thread: one 4-byte store
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k2 = (int)(i % 80) * 2;
+    long m = i / 80;
+    const int ox = (int)(m % Wo); long t = m / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k2 + e;
+      v[e] = 0.f;
+      if (k < 147) {
+        const int c = k / 49, rs = k - c * 49, r = rs / 7, q = rs - r * 7;
+        const int iy = oy * 2 - 3 + r, ix = ox * 2 - 3 + q;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = x[((long)(b * 3 + c) * H + iy) * W + ix];
+      }
+    }
+    *reinterpret_cast<unsigned*>(patches + m * 160 + k2) = pack2(v[0], v[1]);
+  }
+}
+// nn.MaxPool2d(3, 2, 1) on bf16 NHWC (RDM_Net.py:525): 8 channels per thread
+__global__ __launch_bounds__(256) void k_maxpool3s2_bf16(const unsigned short* __restrict__ X, unsigned short* __restrict__ Y, int ldy, int B, int H, int W, int Ho, int Wo, int C8) {
+  const long total = (long)B * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    long pix = i / C8;
+    const int ox = (int)(pix % Wo); long t = pix / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(X + ((long)(b * H + iy) * W + ix) * (C8 * 8) + c);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { best[2 * e] = fmaxf(best[2 * e], bf_lo(u[e])); best[2 * e + 1] = fmaxf(best[2 * e + 1], bf_hi(u[e])); }
+      }
+    *reinterpret_cast<uint4*>(Y + pix * ldy + c) = make_uint4(pack2(best[0], best[1]), pack2(best[2], best[3]), pack2(best[4], best[5]), pack2(best[6], best[7]));
+  }
+}
+// transition front end (RDM_Net.py:527,529,531-532): pad_br -> BN -> ReLU -> 2x2 average, bf16 in / bf16 out, 8 channels per thread
+__global__ __launch_bounds__(256) void k_trans_pool_bf16(const unsigned short* __restrict__ X, int ldx, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         unsigned short* __restrict__ P, int B, int H, int W, int Ho, int Wo, int C8) {
+  const long total = (long)B * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    long pix = i / C8;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float s[8], t[8], acc[8];
+    *reinterpret_cast<float4*>(s) = *reinterpret_cast<const float4*>(sc + c); *reinterpret_cast<float4*>(s + 4) = *reinterpret_cast<const float4*>(sc + c + 4);
+    *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(sh + c); *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(sh + c + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        uint4 v = make_uint4(0, 0, 0, 0);                              // the zero pad row / column is a BatchNorm INPUT
+        if (y < H && x < W) v = *reinterpret_cast<const uint4*>(X + ((long)(b * H + y) * W + x) * ldx + c);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += fmaxf(fmaf(bf_lo(u[e]), s[2 * e], t[2 * e]), 0.f);
+          acc[2 * e + 1] += fmaxf(fmaf(bf_hi(u[e]), s[2 * e + 1], t[2 * e + 1]), 0.f);
+        }
+      }
+    *reinterpret_cast<uint4*>(P + i * 8) = make_uint4(pack2(0.25f * acc[0], 0.25f * acc[1]), pack2(0.25f * acc[2], 0.25f * acc[3]),
+                                                       pack2(0.25f * acc[4], 0.25f * acc[5]), pack2(0.25f * acc[6], 0.25f * acc[7]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int launch_f32_to_bf16_rows(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int cols_pad, hipStream_t s) {
+  const long total = rows * cols_pad;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3((unsigned)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, src, ld_src, static_cast<unsigned short*>(dst), ld_dst, rows, cols, cols_pad);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_pack_w_bf16(const float* w, void* wp, int O, int I, int T, hipStream_t s) {
+  const long total = (long)T * O * I;
+  hipLaunchKernelGGL(k_pack_w_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, w, static_cast<unsigned short*>(wp), O, I, T);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_im2col_stem_bf16(const float* x, void* patches, int B, int H, int W, hipStream_t s) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const long total = (long)B * Ho * Wo * 80;
+  hipLaunchKernelGGL(k_im2col_stem_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, s, x, static_cast<unsigned short*>(patches), B, H, W, Ho, Wo);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_maxpool3s2_bf16(const void* X, void* Y, int ldy, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(k_maxpool3s2_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, s, static_cast<const unsigned short*>(X),
+                     static_cast<unsigned short*>(Y), ldy, B, H, W, Ho, Wo, C / 8);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+int launch_trans_pool_bf16(const void* X, int ldx, const float* sc, const float* sh, void* P, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(k_trans_pool_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, s, static_cast<const unsigned short*>(X), ldx, sc, sh,
+                     static_cast<unsigned short*>(P), B, H, W, Ho, Wo, C / 8);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
+  GemmBf16Args a = a_in;
+  RDM_CHECK_ARG(a.K > 0 && a.K % 8 == 0 && a.ldx % 8 == 0 && a.ldw % 8 == 0, "gemm_bf16: K (%d) and the row strides must be multiples of 8", a.K);
+  RDM_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, "gemm_bf16: N (%d) and ldc must be multiples of 4", a.N);
+  RDM_CHECK_ARG((((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)a.out) & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
+  RDM_CHECK_ARG((a.scale == nullptr) == (a.shift == nullptr) && (((uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.bias) & 15) == 0, "gemm_bf16: bad prologue / bias pointers");
+  const long xb = ((long)(a.M - 1) * a.ldx + a.K) * 2, wb = ((long)(a.N - 1) * a.ldw + a.K) * 2;
+  if (xb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("gemm_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.K * 4);
+  void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, 7);
+  // tiles: 128 x 96 on big grids whose N is (nearly) a multiple of 96, 128 x 48 else; few pixels: 64 x 48 / 32 x 96 (more workgroups)
+  const long t96 = (long)cdiv(a.M, 128) * cdiv(a.N, 96);
+  const bool n96 = (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N;
+#define RDM_G(MT_, NT_, WM_, WN_)                                                                                                         \
+  do {                                                                                                                                      \
+    dim3 grid(cdiv(a.N, NT_ * 16 * WN_), cdiv(a.M, MT_ * 16 * WM_));                                                                        \
+    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, true>), grid, dim3(256), 0, s, a);                                \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, false>), grid, dim3(256), 0, s, a);                                       \
+  } while (0)
+  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2);
+  else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1);
+  else if (a.M > 1024) RDM_G(1, 3, 4, 1);                                // 64 x 48
+  else RDM_G(1, 3, 2, 2);                                                // 32 x 96
+#undef RDM_G
+  profile_end(tk, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
+  Conv3Bf16Args a = a_in;
+  RDM_CHECK_ARG(a.C > 0 && a.C % 8 == 0 && a.ldy % 8 == 0 && a.ldw % 8 == 0 && a.wtap % 8 == 0 && a.ldc % 4 == 0, "conv3x3_bf16: C (%d) and the strides must be multiples of 8", a.C);
+  RDM_CHECK_ARG((((uintptr_t)a.Y | (uintptr_t)a.Wt | (uintptr_t)a.scale | (uintptr_t)a.shift) & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "conv3x3_bf16: operands must be 16-byte aligned");
+  RDM_CHECK_ARG(a.scale && a.shift && a.M == a.B * a.H * a.W, "conv3x3_bf16: needs the BN-ReLU prologue; M must be B*H*W");
+  const long yb = ((long)(a.M - 1) * a.ldy + a.C) * 2, wb = (8L * a.wtap + 47L * a.ldw + a.C) * 2;
+  if (yb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("conv3x3_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
+  a.y_bytes = (unsigned)yb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.C * 4);
+  // 256-pixel tiles when that still gives >= 2 workgroups per CU, else 128, else 64
+  const int bm = (long)cdiv(a.M, 256) >= 512 ? 256 : (long)cdiv(a.M, 128) >= 128 ? 128 : 64;
+  const int halo = bm + 2 * (a.W + 1);
+  const int hl = cdiv(halo * 4, 256);
+  RDM_CHECK_ARG(hl <= 16, "conv3x3_bf16: rows of %d pixels need a halo of %d pixels (> 1024)", a.W, halo);
+  const size_t ldsb = ((size_t)((halo + 7) & ~7) * 32 + 9 * 48 * 32) * 2;
+  RDM_CHECK_ARG(ldsb <= 160 * 1024, "conv3x3_bf16: halo tile of %zu bytes exceeds the 160 KB LDS", ldsb);
+  void* tk = profile_begin(s, 2.0 * a.M * 48.0 * a.C * 9.0, 8);
+  dim3 grid(cdiv(a.M, bm));
+#define RDM_C3(MT_, HL_)                                                                                                                  \
+  do {                                                                                                                                     \
+    if (ldsb > 65536) RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MT_, HL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<MT_, HL_>), grid, dim3(256), ldsb, s, a);                                                       \
+  } while (0)
+#define RDM_C3M(MT_)                                                          \
+  do {                                                                        \
+    if (hl <= 3) RDM_C3(MT_, 3); else if (hl <= 4) RDM_C3(MT_, 4); else if (hl <= 5) RDM_C3(MT_, 5); else if (hl <= 7) RDM_C3(MT_, 7); \
+    else if (hl <= 10) RDM_C3(MT_, 10); else RDM_C3(MT_, 16);                \
+  } while (0)
+  if (bm == 256) RDM_C3M(4); else if (bm == 128) RDM_C3M(2); else RDM_C3M(1);
+#undef RDM_C3M
+#undef RDM_C3
+  profile_end(tk, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace rdm

@@ -856,13 +856,23 @@ struct ProfScope {
   ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind}); } }
 };
 // per-kernel breakdown of the last profile_read()
-constexpr int PROF_KINDS = 7;
+constexpr int PROF_KINDS = 9;
 const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
-    "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel"};
+    "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel",
+    "gemm_bf16_kernel (1x1 forward, bf16 MFMA)", "conv3x3_bf16_kernel (3x3 forward, bf16 MFMA)"};
 double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS];
 int g_kind_n[PROF_KINDS];
 }  // namespace
+
+// the same bracket for launchers outside this file (bf16.hip)
+void* profile_begin(hipStream_t s, double flops, int kind) {
+  if (!g_prof.on) return nullptr;
+  ProfScope* t = new ProfScope(s, flops);
+  t->kind = kind;
+  return t;
+}
+void profile_end(void* ticket, hipStream_t) { delete static_cast<ProfScope*>(ticket); }
 
 static hipEvent_t g_prof_base = nullptr;
 void profile_enable(bool on) {

@@ -17,6 +17,7 @@
 
 #include "rdm_common.h"
 #include "elementwise.h"
+#include "bf16.h"
 
 namespace rdm {
 
@@ -138,6 +139,53 @@ struct NetImpl {
   }
   size_t total;
   int training_saved = 1;
+  // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
+  struct Bf16Layer { size_t w1, w3, bn1, bn2; };
+  std::vector<Bf16Layer> bfl[4];
+  size_t bf_wt[3], bf_tbn[3], bf_stem_w, bf_head_w, bf_wtotal = 0;
+  size_t bf_patches, bf_e1, bf_blk[4], bf_Y, bf_P[3], bf_logits, bf_total = 0;
+  double bf_bytes = 0;      // algorithmic HBM bytes of one bf16 forward (every activation written once, read by its consumers once; weights once)
+  void plan_bf16() {
+    Bump w;
+    for (int b = 0; b < 4; ++b) {
+      bfl[b].resize(kBlocks[b].layers);
+      for (int i = 0; i < kBlocks[b].layers; ++i) {
+        const int cin = kBlocks[b].cin + i * GROWTH;
+        bfl[b][i].w1 = w.take<unsigned short>((size_t)bg[b].cb * cin);
+        bfl[b][i].w3 = w.take<unsigned short>((size_t)9 * GROWTH * bg[b].cb);
+        bfl[b][i].bn1 = w.take<float>(4 * (size_t)cin);
+        bfl[b][i].bn2 = w.take<float>(4 * (size_t)bg[b].cb);
+      }
+    }
+    for (int t = 0; t < 3; ++t) {
+      bf_wt[t] = w.take<unsigned short>((size_t)kTrans[t].cout * kTrans[t].cin);
+      bf_tbn[t] = w.take<float>(4 * (size_t)kTrans[t].cin);
+    }
+    bf_stem_w = w.take<unsigned short>(96 * 160);
+    bf_head_w = w.take<unsigned short>((size_t)180 * 2208);
+    bf_wtotal = (w.off + 255) & ~(size_t)255;
+    Bump a;
+    size_t maxY = 0;
+    bf_patches = a.take<unsigned short>((size_t)M1 * 160);
+    bf_e1 = a.take<unsigned short>((size_t)M1 * 96);
+    for (int b = 0; b < 4; ++b) {
+      bf_blk[b] = a.take<unsigned short>((size_t)bg[b].M * bg[b].ctot);
+      maxY = std::max(maxY, (size_t)bg[b].M * bg[b].cb);
+    }
+    bf_Y = a.take<unsigned short>(maxY);
+    for (int t = 0; t < 3; ++t) bf_P[t] = a.take<unsigned short>((size_t)bg[t + 1].M * kTrans[t].cin);
+    bf_logits = a.take<float>((size_t)bg[3].M * 192);
+    bf_total = (a.off + 255) & ~(size_t)255;
+    // algorithmic traffic: x (f32) + patches w+r + e1 w+r + per layer [prefix read + Y write + Y read + 48-slice write] + transitions + head
+    double by = (double)B * 3 * H0 * W0 * 4 + 2.0 * M1 * 160 * 2 + 2.0 * M1 * 96 * 2 + (double)bg[0].M * 96 * 2;
+    for (int b = 0; b < 4; ++b)
+      for (int i = 0; i < kBlocks[b].layers; ++i)
+        by += (double)bg[b].M * 2 * ((kBlocks[b].cin + i * GROWTH) + 2.0 * bg[b].cb + GROWTH) + 2.0 * ((double)bg[b].cb * (kBlocks[b].cin + i * GROWTH) + 9.0 * GROWTH * bg[b].cb);
+    for (int t = 0; t < 3; ++t)
+      by += (double)bg[t].M * kTrans[t].cin * 2 + 2.0 * bg[t + 1].M * kTrans[t].cin * 2 + (double)bg[t + 1].M * kTrans[t].cout * 2 + 2.0 * kTrans[t].cin * kTrans[t].cout;
+    by += (double)bg[3].M * 2208 * 2 + 2.0 * 180 * 2208 + 2.0 * bg[3].M * 180 * 4;
+    bf_bytes = by;
+  }
 
   void plan() {
     H1 = (H0 + 6 - 7) / 2 + 1; W1 = (W0 + 6 - 7) / 2 + 1;
@@ -208,6 +256,7 @@ struct NetImpl {
     dL = a.take<float>((size_t)bg[3].M * 192);
     tmp64 = a.take<double>(512);
     total = (a.off + 255) & ~(size_t)255;
+    plan_bf16();
   }
 };
 
@@ -614,6 +663,108 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
     a.out = at<float>(ws, n.logits); a.ldc = 192; a.M = g.M; a.N = 180; a.bias = F(T, reg().conv2_b);
     if ((rc = launch_conv_fwd(a, false, EPI_STORE, s)) < 0) return rc;
     if ((rc = launch_nhwc_to_nchw(at<float>(ws, n.logits), 192, logits_nchw, n.B, 180, g.H * g.W, s))) return rc;
+  }
+  return RDM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * reduced-precision forward (BASELINE config 2): bf16 weights / activations, f32 accumulation, eval-mode BatchNorm
+ * --------------------------------------------------------------------------------------------- */
+size_t rdm_net_bf16_weight_bytes(const rdm_net* net) { return net ? reinterpret_cast<const NetImpl*>(net)->bf_wtotal : 0; }
+size_t rdm_net_bf16_workspace_bytes(const rdm_net* net) { return net ? reinterpret_cast<const NetImpl*>(net)->bf_total : 0; }
+double rdm_net_bf16_forward_bytes(const rdm_net* net) { return net ? reinterpret_cast<const NetImpl*>(net)->bf_bytes : 0; }
+
+int rdm_net_bf16_prepare(rdm_net* net, void* const* T, void* wbuf, size_t wbuf_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(net && T && wbuf, "NULL argument");
+  NetImpl& n = *reinterpret_cast<NetImpl*>(net);
+  if (wbuf_bytes < n.bf_wtotal) { set_error("bf16 weight buffer too small: %zu < %zu", wbuf_bytes, n.bf_wtotal); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  RDM_CHECK_ARG(((uintptr_t)wbuf & 255) == 0, "bf16 weight buffer must be 256-byte aligned");
+  for (int i = 0; i < (int)reg().t.size(); ++i)
+    RDM_CHECK_ARG(T[i] != nullptr || reg().t[i].numel == 0, "tensor %d (%s) is NULL", i, reg().t[i].name.c_str());
+  hipStream_t s = stream;
+  int rc;
+  auto affine = [&](const BnIdx& b, size_t off, int C) {      // eval-mode BatchNorm folded to (scale, shift): running statistics
+    float* d = at<float>(wbuf, off);
+    return launch_bn_finalize(nullptr, nullptr, 1.0, F(T, b.w), F(T, b.b), F(T, b.rm), F(T, b.rv), nullptr, d, d + C, d + 2 * C, d + 3 * C, C, 0, s);
+  };
+  for (int b = 0; b < 4; ++b)
+    for (int i = 0; i < kBlocks[b].layers; ++i) {
+      const LayerIdx& L = reg().layers[b][i];
+      const NetImpl::Bf16Layer& W = n.bfl[b][i];
+      const int cin = kBlocks[b].cin + i * GROWTH, cb = n.bg[b].cb;
+      if ((rc = launch_f32_to_bf16_rows(F(T, L.conv1), cin, at<char>(wbuf, W.w1), cin, cb, cin, cin, s))) return rc;
+      if ((rc = launch_pack_w_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), GROWTH, cb, 9, s))) return rc;
+      if ((rc = affine(L.bn1, W.bn1, cin))) return rc;
+      if ((rc = affine(L.bn2, W.bn2, cb))) return rc;
+    }
+  for (int t = 0; t < 3; ++t) {
+    if ((rc = launch_f32_to_bf16_rows(F(T, reg().trans_conv[t]), kTrans[t].cin, at<char>(wbuf, n.bf_wt[t]), kTrans[t].cin, kTrans[t].cout, kTrans[t].cin, kTrans[t].cin, s))) return rc;
+    if ((rc = affine(reg().trans_bn[t], n.bf_tbn[t], kTrans[t].cin))) return rc;
+  }
+  if ((rc = launch_f32_to_bf16_rows(F(T, reg().stem_w), 147, at<char>(wbuf, n.bf_stem_w), 160, 96, 147, 160, s))) return rc;   // K 147 -> 160, zero padded
+  if ((rc = launch_f32_to_bf16_rows(F(T, reg().conv2_w), 2208, at<char>(wbuf, n.bf_head_w), 2208, 180, 2208, 2208, s))) return rc;
+  return RDM_OK;
+}
+
+int rdm_net_forward_bf16(rdm_net* net, const float* x, void* const* T, const void* wbuf, size_t wbuf_bytes, void* ws, size_t ws_bytes,
+                         float* logits_nchw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(net && x && T && wbuf && ws && logits_nchw, "NULL argument");
+  NetImpl& n = *reinterpret_cast<NetImpl*>(net);
+  if (wbuf_bytes < n.bf_wtotal) { set_error("bf16 weight buffer too small: %zu < %zu", wbuf_bytes, n.bf_wtotal); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  if (ws_bytes < n.bf_total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.bf_total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  RDM_CHECK_ARG((((uintptr_t)ws | (uintptr_t)wbuf) & 255) == 0, "workspace and weight buffer must be 256-byte aligned");
+  hipStream_t s = stream;
+  void* wb = const_cast<void*>(wbuf);
+  int rc;
+  // stem: 7x7/s2 as im2col + GEMM (K = 147 padded to 160) + bias, 3x3/s2 max-pool into the first 96 channels of block 0
+  if ((rc = launch_im2col_stem_bf16(x, at<char>(ws, n.bf_patches), n.B, n.H0, n.W0, s))) return rc;
+  {
+    GemmBf16Args a{};
+    a.X = at<char>(ws, n.bf_patches); a.ldx = 160; a.K = 160;
+    a.W = at<char>(wb, n.bf_stem_w); a.ldw = 160;
+    a.out = at<char>(ws, n.bf_e1); a.ldc = 96; a.M = n.M1; a.N = 96; a.bias = F(T, reg().stem_b);
+    if ((rc = launch_gemm_bf16(a, false, s))) return rc;
+  }
+  if ((rc = launch_maxpool3s2_bf16(at<char>(ws, n.bf_e1), at<char>(ws, n.bf_blk[0]), n.bg[0].ctot, n.B, n.H1, n.W1, 96, s))) return rc;
+  for (int b = 0; b < 4; ++b) {
+    const BlockGeom& g = n.bg[b];
+    unsigned short* blk = at<unsigned short>(ws, n.bf_blk[b]);
+    for (int i = 0; i < kBlocks[b].layers; ++i) {
+      const NetImpl::Bf16Layer& W = n.bfl[b][i];
+      const int cin = kBlocks[b].cin + i * GROWTH;
+      const float* bn1 = at<float>(wb, W.bn1);
+      const float* bn2 = at<float>(wb, W.bn2);
+      GemmBf16Args a{};                                      // BN-ReLU -> 1x1 (cin -> cb)
+      a.X = blk; a.ldx = g.ctot; a.K = cin; a.scale = bn1; a.shift = bn1 + cin;
+      a.W = at<char>(wb, W.w1); a.ldw = cin;
+      a.out = at<char>(ws, n.bf_Y); a.ldc = g.cb; a.M = g.M; a.N = g.cb;
+      if ((rc = launch_gemm_bf16(a, false, s))) return rc;
+      Conv3Bf16Args c{};                                     // BN-ReLU -> 3x3 (cb -> 48), written in place behind the block's channels
+      c.Y = at<char>(ws, n.bf_Y); c.ldy = g.cb; c.C = g.cb; c.scale = bn2; c.shift = bn2 + g.cb;
+      c.Wt = at<char>(wb, W.w3); c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
+      c.out = blk + cin; c.ldc = g.ctot; c.B = n.B; c.H = g.H; c.W = g.W; c.M = g.M;
+      if ((rc = launch_conv3x3_bf16(c, s))) return rc;
+    }
+    if (b < 3) {
+      const BlockGeom& gn = n.bg[b + 1];
+      const int C = kTrans[b].cin, Co = kTrans[b].cout;
+      const float* bn = at<float>(wb, n.bf_tbn[b]);
+      if ((rc = launch_trans_pool_bf16(blk, g.ctot, bn, bn + C, at<char>(ws, n.bf_P[b]), n.B, g.H, g.W, C, s))) return rc;
+      GemmBf16Args a{};
+      a.X = at<char>(ws, n.bf_P[b]); a.ldx = C; a.K = C;
+      a.W = at<char>(wb, n.bf_wt[b]); a.ldw = C;
+      a.out = at<char>(ws, n.bf_blk[b + 1]); a.ldc = gn.ctot; a.M = gn.M; a.N = Co;
+      if ((rc = launch_gemm_bf16(a, false, s))) return rc;
+    }
+  }
+  {
+    const BlockGeom& g = n.bg[3];                            // d_1.conv2: 1x1 2208 -> 180 + bias, f32 logits
+    GemmBf16Args a{};
+    a.X = at<char>(ws, n.bf_blk[3]); a.ldx = g.ctot; a.K = g.ctot;
+    a.W = at<char>(wb, n.bf_head_w); a.ldw = g.ctot;
+    a.out = at<char>(ws, n.bf_logits); a.ldc = 192; a.M = g.M; a.N = 180; a.bias = F(T, reg().conv2_b);
+    if ((rc = launch_gemm_bf16(a, true, s))) return rc;
+    if ((rc = launch_nhwc_to_nchw(at<float>(ws, n.bf_logits), 192, logits_nchw, n.B, 180, g.H * g.W, s))) return rc;
   }
   return RDM_OK;
 }

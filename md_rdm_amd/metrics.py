@@ -35,7 +35,11 @@ class MetricComputation:
             dist.all_reduce(out)
         out = out.cpu()
         assert out[0] > 0, "invalid target!"
-        values = [float(out[_SLOTS[m]] / out[0]) for m in self.names]
+        # delta1-3 are float32 in the reference: `(maxRatio < 1.25 ** k).float().mean()` (metrics.py:79-89) - an exact integer count
+        # divided in float32; the other metrics stay in the dtype of the inputs (float64 from validation_step)
+        n = float(out[0])
+        values = [float(torch.tensor(float(out[_SLOTS[m]]), dtype=torch.float32) / n) if m.startswith("delta") else float(out[_SLOTS[m]]) / n
+                  for m in self.names]
         self.count += 1
         for i, v in enumerate(values):
             self.sum[i] += v

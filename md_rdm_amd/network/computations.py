@@ -340,19 +340,33 @@ def quadratic_als(sparse_m, cuda, n=3, limit=30, debug=False):
     return _als(sparse_m, 1, B, H, W, limit).view(B, 1, s, s)
 
 
+def _pages(t, page):
+    """(B,1,S,S) -> list of (S/page)^2 row-major (B,1,page,page) pages, dtype kept (pure indexing: a device view + one copy)."""
+    B, _, S, _ = t.shape
+    r = S // page
+    return list(t.reshape(B, 1, r, page, r, page).permute(2, 4, 0, 1, 3, 5).reshape(r * r, B, 1, page, page).contiguous())
+
+
 def split_matrix(d_n, d_n_1):
-    """computations.py:201-216."""
+    """computations.py:201-216: 16x16 pages of d_n and the matching 8x8 pages of d_{n-1}, each in its own dtype (the reference
+    hands the float64 coarse map through unchanged).  float32 maps go through rdm_page_split_f32."""
     _need_gpu(d_n)
     B, _, S, _ = d_n.shape
-    L = _lib.lib()
-    a = d_n.float().contiguous()
-    b = d_n_1.float().contiguous()
-    P = (S // 16) ** 2
-    pa = torch.empty(P, B, 1, 16, 16, dtype=torch.float32, device=a.device)
-    pb = torch.empty(P, B, 1, 8, 8, dtype=torch.float32, device=a.device)
-    _lib.check(L.rdm_page_split_f32(_lib.ptr(a), _lib.ptr(pa), B, S, 16, _lib.stream()))
-    _lib.check(L.rdm_page_split_f32(_lib.ptr(b), _lib.ptr(pb), B, S // 2, 8, _lib.stream()))
-    return list(pa), list(pb)
+    if d_n.dtype != torch.float32:
+        pa = _pages(d_n, 16)
+    else:
+        a = d_n.contiguous()
+        pa = torch.empty((S // 16) ** 2, B, 1, 16, 16, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.lib().rdm_page_split_f32(_lib.ptr(a), _lib.ptr(pa), B, S, 16, _lib.stream()))
+        pa = list(pa)
+    if d_n_1.dtype != torch.float32:
+        pb = _pages(d_n_1, 8)
+    else:
+        b = d_n_1.contiguous()
+        pb = torch.empty((S // 16) ** 2, B, 1, 8, 8, dtype=torch.float32, device=b.device)
+        _lib.check(_lib.lib().rdm_page_split_f32(_lib.ptr(b), _lib.ptr(pb), B, S // 2, 8, _lib.stream()))
+        pb = list(pb)
+    return pa, pb
 
 
 def reconstruct(splits):

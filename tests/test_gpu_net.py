@@ -108,15 +108,19 @@ def test_rectangular_228x304_head_vs_reference(dev, net_gold):
 
 
 def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gold):
-    """Backward parity, tensor by tensor (491 tensors with a gradient):
-    (a) element-wise: max|g_hip - g_f64| / max|g_f64| <= K_ELEM x the same quantity of the float32 ORACLE for that tensor
-        (+ a float-rounding floor) - each tensor is held to its OWN noise level, nothing is pooled;
-    (b) norms: | ||g_hip|| - N_ref | / N_ref, N_ref = the norm the REFERENCE itself produced for that tensor (fixture
-        train228_grad_norm), bounded by K_NORM x that tensor's own |(||g_f32|| - ||g_f64||)| / ||g_f64|| (+ floor).
-    The reference and the HIP path are two float32 evaluations of one piecewise-linear function: each deviates from the float64
-    value by that tensor's noise, so their mutual distance is bounded by a small multiple of it."""
+    """Backward parity, tensor by tensor (all 485 tensors that receive a gradient; nothing is pooled into one maximum):
+    (a) relative L2 error w.r.t. the float64 oracle:  ||g_hip - g_f64|| / ||g_f64||  <=  2 x (the float32 ORACLE's own error on
+        THAT tensor) + 1.5e-2;
+    (b) gradient NORM against the norm the REFERENCE itself produced for that tensor (fixture train228_grad_norm, written by
+        tests/golden/make_golden.py from the reference's autograd):  | ||g_hip|| - N_ref | / N_ref  <=  3 x (that tensor's own
+        float32-oracle norm error | ||g_f32|| - ||g_f64|| | / ||g_f64||) + 1.5e-3   (the CPU oracle is held to 2e-3 flat).
+    Why a floor next to the tensor's own error: the loss is piecewise linear and two float32 evaluations differ by discrete ReLU
+    flips (tests/test_oracle_net.py::test_f32_gradient_noise_floor).  Measured on MI355X: every tensor sits at a relative L2
+    error of 0.6-1.5 % in BOTH float32 evaluations (medians 7.8e-3 HIP / 7.3e-3 oracle, ratio median 0.99, p90 1.14) - except
+    the handful the float32 oracle happens to evaluate without a flip (d_1 denselayer24: 2e-5), where its own error says nothing
+    about the noise level; the floors are 2x the typical L2 level and 4x the p90 norm error."""
     from md_rdm_amd import harness
-    K_ELEM, FLOOR_ELEM, K_NORM, FLOOR_NORM = 4.0, 2e-4, 4.0, 5e-4
+    K_L2, FLOOR_L2, K_NORM, FLOOR_NORM = 2.0, 1.5e-2, 3.0, 1.5e-3
     B = 2
     x, y = filler.synthetic_batch(B, 228, 228, seed=SEED["train228"])
     m = make_model(dev)
@@ -127,7 +131,7 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
     r64 = onet.training_step(sd64, torch.from_numpy(x).double(), y)
     assert abs(loss.item() - r64["loss_all"]) < 1e-4 * abs(r64["loss_all"])
     gold_norm = dict(zip([str(n) for n in net_gold["train228_grad_names"]], net_gold["train228_grad_norm"]))
-    checked, report = 0, []
+    report = []
     for n, p in m.named_parameters():
         g64 = r64["grads"].get(n)
         if g64 is None:
@@ -136,16 +140,18 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
             continue
         g = p.grad.cpu().double()
         g32 = r32["grads"][n].double()
-        den = g64.abs().max().item() + 1e-30
-        e_hip, e_f32 = (g - g64).abs().max().item() / den, (g32 - g64).abs().max().item() / den
-        n64 = g64.norm().item()
-        en_f32 = abs(g32.norm().item() - n64) / n64
-        en_hip = abs(g.norm().item() - gold_norm[n]) / gold_norm[n]
-        report.append((n, e_hip, e_f32, en_hip, en_f32))
-        checked += 1
-    assert checked == 487 or checked >= 480, checked                           # 491 parameter tensors minus d_1.conv1.* and the empty f4..f7
-    bad = [(n, eh, ef, nh, nf) for n, eh, ef, nh, nf in report if eh > K_ELEM * ef + FLOOR_ELEM or nh > K_NORM * nf + FLOOR_NORM]
-    assert not bad, "per-tensor gradient parity failed for %d tensors, worst: %r" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])
+        n64 = g64.norm().item() + 1e-300
+        report.append((n, (g - g64).norm().item() / n64, (g32 - g64).norm().item() / n64,
+                       abs(g.norm().item() - gold_norm[n]) / gold_norm[n], abs(g32.norm().item() - n64) / n64, p.numel()))
+    assert len(report) == 485, len(report)                                     # 491 parameter tensors minus d_1.conv1.{weight,bias} and the empty f4..f7
+    import os
+    if os.environ.get("RDM_GRAD_REPORT"):                                       # development aid: dump the per-tensor table
+        import json
+        with open(os.environ["RDM_GRAD_REPORT"], "w") as fh:
+            json.dump(report, fh)
+    bad = [t for t in report if t[1] > K_L2 * t[2] + FLOOR_L2 or t[3] > K_NORM * t[4] + FLOOR_NORM]
+    assert not bad, "per-tensor gradient parity failed for %d tensors (name, l2 hip, l2 f32, norm hip, norm f32, numel): %r" % (
+        len(bad), sorted(bad, key=lambda t: -t[1])[:5])
 
 
 def test_direct_gradient_mode_and_fused_adamw(dev):
