@@ -36,7 +36,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path); gloo only to rehearse N>1 on a one-GPU box")
+    ap.add_argument("--workload", default="train", choices=["train", "fwd_bf16"],
+                    help="train = the headline metric (BASELINE configs[2]); fwd_bf16 = BASELINE configs[1], batch=8 forward-only bf16")
     args = ap.parse_args()
+    if args.workload == "fwd_bf16":
+        return bench_fwd_bf16(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,7 +124,7 @@ def main():
         peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
         achieved = algo / (ms.value * 1e-3) / 1e12
         per_kernel = []
-        for kind in range(7):
+        for kind in range(9):
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:
@@ -161,6 +165,132 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_fwd_bf16(args):
+    """BASELINE configs[1]: "NYU-v2 batch=8 forward-only bf16, 1xMI355X".  A step = one eval-mode DepthEstimationNet.forward (conv
+    stack on the bf16 MFMA path + DORN head + decomposition tail) on a synthetic batch resident in HBM."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:                                           # inference shards by sample: independent replicas, no data-path collective
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    from md_rdm_amd import _lib, filler
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    L = _lib.lib()
+    if os.environ.get("RDM_VARIANT"):                     # development A/B switch, 0 = shipped
+        L.rdm_debug_variant(int(os.environ["RDM_VARIANT"]))
+    B = 8 if args.batch == 16 else args.batch
+    H, W = args.height, args.width
+    model = DepthEstimationNet()
+    filler.fill_state_dict(model.state_dict())
+    model = model.to(dev).eval().set_precision("bf16")
+    x, _ = filler.synthetic_batch(B, H, W, seed=1234 + rank)
+    xg = torch.from_numpy(x).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(xg)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # conv-stack-only time (the tail is ~10 small launches): same K steps of the native forward alone
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        with torch.no_grad():
+            model._native_forward_bf16(xg)
+    torch.cuda.synchronize()
+    stack_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    roof = None
+    if not args.no_roofline:
+        L.rdm_profile_enable(1)
+        for _ in range(args.steps):
+            with torch.no_grad():
+                model._native_forward_bf16(xg)
+        torch.cuda.synchronize()
+        ms_sum, ms, fl, n = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(L.rdm_profile_read(C.byref(ms_sum), C.byref(ms), C.byref(fl), C.byref(n)))
+        L.rdm_profile_enable(0)
+        h = model._plan(B, H, W)[0]
+        PEAK_MFMA, PEAK_HBM = 2500.0, 8000.0                     # dense bf16 MFMA TFLOP/s, HBM3E GB/s (MI355X_MICROARCH.md)
+        per_kernel = []
+        for kind in (7, 8):
+            nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
+            _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
+            kby = L.rdm_profile_kind_bytes(kind)
+            if kn.value:
+                sec = kms.value * 1e-3
+                per_kernel.append({"kernel": nm.value.decode(), "launches_per_step": kn.value // args.steps, "avg_launch_us": round(kms.value / kn.value * 1e3, 2),
+                                   "ms_sum_per_step": round(kms.value / args.steps, 3), "tflops": round(kfl.value / sec / 1e12, 1),
+                                   "mfma_frac": round(kfl.value / sec / 1e12 / PEAK_MFMA, 4), "algorithmic_GBps": round(kby / sec / 1e9, 1),
+                                   "hbm_frac": round(kby / sec / 1e9 / PEAK_HBM, 4), "flop_per_byte": round(kfl.value / max(kby, 1), 1)})
+        per_kernel.sort(key=lambda r: -r["ms_sum_per_step"])
+        dom = per_kernel[0]
+        bound = "mfma" if dom["mfma_frac"] >= dom["hbm_frac"] else "hbm"       # the roofline the dominant kernel sits closer to
+        algo_fl = L.rdm_net_forward_flops(h)
+        roof = {"bound": bound, "kernel": dom["kernel"],
+                "achieved": dom["tflops"] if bound == "mfma" else dom["algorithmic_GBps"], "peak": PEAK_MFMA if bound == "mfma" else PEAK_HBM,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": dom["mfma_frac"] if bound == "mfma" else dom["hbm_frac"], "traffic": None,
+                "per_kernel": per_kernel, "conv_kernel_ms_per_step": round(ms_sum.value / args.steps, 3), "conv_launches_per_step": n.value // args.steps,
+                "whole_stack": {"algorithmic_tflop_per_step": round(algo_fl / 1e12, 4), "algorithmic_GB_per_step": round(L.rdm_net_bf16_forward_bytes(h) / 1e9, 3),
+                                "stack_ms_per_step": round(stack_ms, 3), "mfma_frac": round(algo_fl / (stack_ms * 1e-3) / 1e12 / PEAK_MFMA, 4),
+                                "hbm_frac": round(L.rdm_net_bf16_forward_bytes(h) / (stack_ms * 1e-3) / 1e9 / PEAK_HBM, 4)},
+                "timing": "HIP events on the launch stream around every bf16 conv launch over K further forwards run right after the timed region"}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_forward(H, W)
+    if rank == 0:
+        out_line = {"metric": "depth-maps/sec NYU 228x304 batch=8 forward bf16", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": f"NYU-v2 {H}x{W} batch={B}/GPU forward-only bf16 (eval-mode DepthEstimationNet.forward: conv stack + DORN head + decomposition tail)",
+                               "global_batch": B * world, "parallelism": f"replicas{world}"},
+                    "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out_line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_forward(H, W, batch=2, iters=3):
+    """The oracle's eval-mode forward (PyTorch-CPU restatement of the reference, float32) on the host cores."""
+    from md_rdm_amd import filler
+    from oracle import rdm_net_cpu as onet
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, int(os.environ.get("RDM_CPU_THREADS", "16"))))
+    torch.set_num_threads(n)
+    sd = onet.new_state_dict(filler.state_value)
+    x, _ = filler.synthetic_batch(batch, H, W, seed=1234)
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        onet.forward(sd, xt, training=False)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            onet.forward(sd, xt, training=False)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} eval-mode forwards at batch {batch}, {H}x{W}, float32 (the CPU has no bf16 conv path worth timing), after 1 warm-up"}
 
 
 def cpu_baseline(H, W, batch=2, iters=2):

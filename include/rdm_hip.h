@@ -48,9 +48,11 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..6 (returns RDM_ERR_ARG beyond), *name = static
- * string naming the kernel, summed duration (ms), executed FLOPs and launch count of that kernel. */
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..8 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the f32 MFMA kernels,
+ * 7-8 the bf16 forward kernels), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
+/* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for kinds 0-6) */
+double rdm_profile_kind_bytes(int32_t kind);
 /* development switch for in-process A/B timing of the measured alternatives DESIGN.md 4.1 cites (0 = shipped):
  * 7 generic instead of halo 3x3, 8 no forward pipelining, 9 generic instead of row wgrad, 11 hardware block order,
  * 13 128x96 wgrad tiles only, 14 default-priority side stream, 16/20 256x48 tiles on 1x1 convs, 21 256-pixel halo tiles only,
@@ -98,6 +100,24 @@ int rdm_pack_conv_weight(const float* w_oihw, float* w_packed, int32_t out_c, in
                          int32_t out_c_padded, rdm_stream_t stream);
 int rdm_unpack_conv_weight(const float* w_packed, float* w_oihw, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,
                            int32_t out_c_padded, rdm_stream_t stream);
+
+/* bf16 operators of the reduced-precision forward (rdm_net_forward_bf16 below enqueues the same kernels; reference: the
+ * mixed-precision convolutions of train.py:11,57-58 over network/RDM_Net.py:144,524-531).  bf16 = the upper 16 bits of an IEEE
+ * float32, round-to-nearest-even; v_mfma_f32_16x16x32_bf16 with f32 accumulation.
+ *   rdm_gemm_bf16     out[m][n] = bias[n] + sum_k f(x[m][k]) * w[n][k], f = relu(x*scale[k]+shift[k]) (rounded to bf16) when scale != NULL.
+ *                     x (M, ldx) bf16, w (N, ldw) bf16, out (M, ldc) bf16 or f32 (out_f32 != 0); K, ldx, ldw multiples of 8; N, ldc of 4.
+ *                     workspace (optional f32 scratch, 256-byte aligned, up to 8*M*N floats are used): lets a few-row / long-K product
+ *                     (M <= 1024) split K over the grid; partial sums are reduced in a fixed order (deterministic).
+ *   rdm_conv3x3_bf16  3x3 / stride 1 / pad 1 conv with 48 outputs: y (B,H,W, ldy) bf16 with the BN-ReLU prologue over its `channels`
+ *                     (multiple of 8), w [9][48][channels] bf16, out (B*H*W, ldc) bf16 - typically a 48-channel slice of a wider buffer.
+ *                     workspace (optional, 256-byte aligned): f32 scratch for a K-split that fills the chip when B*H*W is small -
+ *                     partial sums are stored per split and reduced in a fixed order (deterministic); any size is accepted, the split is
+ *                     sized to it (rdm_conv3x3_bf16_workspace_bytes gives the amount the heuristic would like). */
+int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* bias,
+                  void* out, int32_t ldc, int32_t m, int32_t n, int32_t out_f32, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w);
+int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* scale, const float* shift, const void* w_packed, void* out,
+                     int32_t ldc, int32_t batch, int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm / pooling pieces of the conv stack as operators (the plan below enqueues the same kernels).

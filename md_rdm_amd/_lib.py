@@ -26,6 +26,7 @@ _SIGNATURES = {
     "rdm_debug_variant": (None, [i32]),
     "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind": (C.c_int, [i32, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
+    "rdm_profile_kind_bytes": (f64, [i32]),
     "rdm_nyu_preprocess_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "rdm_nyu_preprocess": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "rdm_microbench_copy": (C.c_int, [vp, vp, i64, vp]),
@@ -35,6 +36,9 @@ _SIGNATURES = {
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_gemm_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "rdm_conv3x3_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "rdm_conv3x3_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "rdm_bn_stats": (C.c_int, [vp, i32, i64, i32, vp, vp, vp]),
     "rdm_bn_finalize": (C.c_int, [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "rdm_bn_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, vp, i64, i32, vp, vp, vp]),

@@ -1,9 +1,11 @@
 // C-ABI plumbing: thread-local error string, argument validation and the op-level conv entry
 // points declared in include/rdm_hip.h.  No torch types cross this boundary.
 #include <stdarg.h>
+#include <algorithm>
 
 #include "rdm_common.h"
 #include "elementwise.h"
+#include "bf16.h"
 
 namespace rdm {
 extern int g_variant;
@@ -49,6 +51,9 @@ int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* fl
   if (launches) *launches = n;
   return rc;
 }
+
+/* algorithmic HBM bytes (operands read once + result written once) of the launches of `kind` in the last rdm_profile_read(); 0 for the f32 kinds */
+double rdm_profile_kind_bytes(int32_t kind) { return profile_kind_bytes(kind); }
 
 size_t rdm_nyu_preprocess_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t resized_h, int32_t resized_w, int32_t out_w) {
   return nyu_preprocess_workspace_bytes(batch, in_h, in_w, resized_h, resized_w, out_w);
@@ -119,6 +124,35 @@ int rdm_pack_conv_weight(const float* w, float* wp, int32_t out_c, int32_t in_c,
 int rdm_unpack_conv_weight(const float* wp, float* w, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw, int32_t out_c_padded, rdm_stream_t stream) {
   RDM_CHECK_ARG(w && wp && out_c > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c_padded >= out_c, "unpack_conv_weight: bad argument");
   return launch_unpack_w(wp, w, out_c, in_c, kh * kw, out_c_padded, stream);
+}
+
+int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* bias,
+                  void* out, int32_t ldc, int32_t m, int32_t n, int32_t out_f32, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(x && w && out && m > 0 && n > 0 && k > 0 && ldx >= k && ldw >= k && ldc >= n, "gemm_bf16: bad argument");
+  RDM_CHECK_ARG(!workspace || ((uintptr_t)workspace & 255) == 0, "gemm_bf16: workspace must be 256-byte aligned");
+  GemmBf16Args a{};
+  a.X = x; a.ldx = ldx; a.K = k; a.scale = scale; a.shift = shift; a.W = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldc = ldc; a.M = m; a.N = n;
+  a.partial = static_cast<float*>(workspace); a.partial_floats = workspace ? workspace_bytes / sizeof(float) : 0;
+  return launch_gemm_bf16(a, out_f32 != 0, stream);
+}
+
+size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w) {
+  if (channels <= 0 || batch <= 0 || h <= 0 || w <= 0) return 0;
+  const long M = (long)batch * h * w;
+  const int split = std::min(std::max(cdiv(channels, 32) / 2, 1), 16);
+  return split > 1 ? (size_t)split * M * 48 * sizeof(float) : 0;
+}
+
+int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* scale, const float* shift, const void* w_packed, void* out,
+                     int32_t ldc, int32_t batch, int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(!workspace || ((uintptr_t)workspace & 255) == 0, "conv3x3_bf16: workspace must be 256-byte aligned");
+  RDM_CHECK_ARG(y && w_packed && out && scale && shift && batch > 0 && h > 0 && w > 0 && channels > 0 && ldy >= channels && ldc >= 48, "conv3x3_bf16: bad argument");
+  RDM_CHECK_ARG((long)batch * h * w < (1L << 30), "conv3x3_bf16: too many pixels for 32-bit indices");
+  Conv3Bf16Args a{};
+  a.Y = y; a.ldy = ldy; a.C = channels; a.scale = scale; a.shift = shift; a.Wt = w_packed; a.wtap = 48L * channels; a.ldw = channels;
+  a.out = static_cast<unsigned short*>(out); a.ldc = ldc; a.B = batch; a.H = h; a.W = w; a.M = batch * h * w;
+  a.partial = static_cast<float*>(workspace); a.partial_floats = workspace ? workspace_bytes / sizeof(float) : 0;
+  return launch_conv3x3_bf16(a, stream);
 }
 
 static int check_nhwc(const void* p, int ld, int channels, const char* what) {

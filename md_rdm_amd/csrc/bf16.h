@@ -9,6 +9,7 @@ struct GemmBf16Args {        // out[m][n] = bias[n] + sum_k f(X[m][k]) * W[n][k]
   const void* W; int ldw;                  // bf16 weights [N][ldw]
   void* out; int ldc; int M, N;            // bf16 (or f32) [M][ldc]
   const float* bias;                       // optional f32[N]
+  float* partial; size_t partial_floats;   // optional f32 scratch for a K-split ([split][M][N] partial sums + one tiny reduction launch)
   unsigned x_bytes, w_bytes, p_bytes;      // set by the launcher (buffer descriptors)
 };
 
@@ -18,6 +19,8 @@ struct Conv3Bf16Args {       // out[m][n] = sum_{tap,c} relu(Y[pix(m,tap)][c]*sc
   const void* Wt; long wtap; int ldw;      // bf16 [9][48][ldw]
   unsigned short* out; int ldc;            // bf16 [M][ldc] (a 48-channel slice of the block buffer)
   int B, H, W, M;
+  float* partial; size_t partial_floats;   // optional f32 scratch for the K-split: [split][M][48] partial sums, reduced by a second (tiny) launch
+  int split;                               // set by the launcher
   unsigned y_bytes, w_bytes, p_bytes;
 };
 

@@ -30,6 +30,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0xFFFFFFFFu;
+extern int g_variant;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t srd(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -73,13 +74,16 @@ __device__ __forceinline__ void xcd_order(int& bx, int& by) {      // see igemm.
 // Block = 4 wave64s (WM x WN), wave tile (MT*16 pixels) x (NT*16 channels), K walked in 64-deep steps (2 MFMA k-steps).
 // global -> registers (next step's loads in flight under this step's MFMAs) -> BN-ReLU -> swizzled LDS, 2 buffers, 1 barrier / step.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool OUT_F32>
+template <int MT, int NT, int WM, int WN, int BK, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
-  constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN, BK = 64;
-  constexpr int XL = (BM + 31) / 32, WL = (BN + 31) / 32;          // 16-byte chunks per thread and step
+  constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
+  constexpr int CH = BK / 8, RP = 256 / CH;                          // 16-byte chunks per row; rows covered by one pass of the 256 threads
+  constexpr int XL = (BM + RP - 1) / RP, WL = (BN + RP - 1) / RP;    // chunks per thread and step
   __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (BM + BN) * BK];
   unsigned short* const Xs0 = lds;
   unsigned short* const Ws0 = lds + 2 * BM * BK;
+  // conflict-free chunk swizzles (header): 128-byte rows (BK 64): c ^ ((row >> 1) & 7); 64-byte rows (BK 32): c ^ (((row >> 2) & 1) << 1)
+  auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 2) & 1) << 1); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
@@ -91,50 +95,53 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
   const __amdgpu_buffer_rsrc_t srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
   const bool bnrelu = p.scale != nullptr;
 
-  const int ch = tid & 7, r0 = tid >> 3;                              // this thread's chunk column and first row
+  const int ch = tid % CH, r0 = tid / CH;                             // this thread's chunk column and first row
   unsigned xoff[XL], woff[WL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
-    const int r = r0 + 32 * i, m = m0 + r;
+    const int r = r0 + RP * i, m = m0 + r;
     xoff[i] = (r < BM && m < p.M) ? (unsigned)m * (unsigned)(p.ldx * 2) + (unsigned)(ch * 16) : OOB;
   }
 #pragma unroll
   for (int i = 0; i < WL; ++i) {
-    const int r = r0 + 32 * i, n = n0 + r;
+    const int r = r0 + RP * i, n = n0 + r;
     woff[i] = (r < BN && n < p.N) ? (unsigned)n * (unsigned)(p.ldw * 2) + (unsigned)(ch * 16) : OOB;
   }
-  uint4 rx[XL], rw[WL];
-  float4 sa, sb, ta, tb;
-  auto load_step = [&](int kt) {
+  // Two register stages: the loads of step kt+2 are issued while step kt is multiplied, so every load has two full steps
+  // (2 x [MFMAs + LDS staging + barrier]) to land - with 16x the f32 MFMA rate a step is far shorter than an L2 / HBM round trip,
+  // and one stage of prefetch left the kernel waiting on memory latency (measured 0.6-1.5 us per 64-deep step).
+  struct Stage { uint4 rx[XL]; uint4 rw[WL]; float4 sa, sb, ta, tb; };
+  Stage SA, SB;
+  auto load_step = [&](int kt, Stage& S) {
     const int k0 = kt * BK + ch * 8;
     const bool kok = k0 < p.K;                                        // K is a multiple of 8: a chunk is all in or all out
     const unsigned kb = (unsigned)(kt * BK * 2);
 #pragma unroll
-    for (int i = 0; i < XL; ++i) rx[i] = bld(srdX, (kok && xoff[i] != OOB) ? xoff[i] + kb : OOB);
+    for (int i = 0; i < XL; ++i) S.rx[i] = bld(srdX, (kok && xoff[i] != OOB) ? xoff[i] + kb : OOB);
 #pragma unroll
-    for (int i = 0; i < WL; ++i) rw[i] = bld(srdW, (kok && woff[i] != OOB) ? woff[i] + kb : OOB);
+    for (int i = 0; i < WL; ++i) S.rw[i] = bld(srdW, (kok && woff[i] != OOB) ? woff[i] + kb : OOB);
     if (bnrelu) {
       const unsigned po = kok ? (unsigned)(k0 * 4) : OOB;
-      sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
-      ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+      S.sa = bldf(srdS, po); S.sb = bldf(srdS, po == OOB ? OOB : po + 16);
+      S.ta = bldf(srdT, po); S.tb = bldf(srdT, po == OOB ? OOB : po + 16);
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const Stage& S) {
     unsigned short* Xs = Xs0 + buf * BM * BK;
     unsigned short* Ws = Ws0 + buf * BN * BK;
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-      const int r = r0 + 32 * i;
+      const int r = r0 + RP * i;
       if (r < BM) {
-        uint4 v = rx[i];
-        if (bnrelu) v = bnrelu8(v, sa, sb, ta, tb);
-        *reinterpret_cast<uint4*>(Xs + r * BK + ((ch ^ ((r >> 1) & 7)) << 3)) = v;
+        uint4 v = S.rx[i];
+        if (bnrelu) v = bnrelu8(v, S.sa, S.sb, S.ta, S.tb);
+        *reinterpret_cast<uint4*>(Xs + r * BK + ((ch ^ swz(r)) << 3)) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-      const int r = r0 + 32 * i;
-      if (r < BN) *reinterpret_cast<uint4*>(Ws + r * BK + ((ch ^ ((r >> 1) & 7)) << 3)) = rw[i];
+      const int r = r0 + RP * i;
+      if (r < BN) *reinterpret_cast<uint4*>(Ws + r * BK + ((ch ^ swz(r)) << 3)) = S.rw[i];
     }
   };
 
@@ -144,19 +151,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  const int sw = (l16 >> 1) & 7;                                      // tile row bases are multiples of 16
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) load_step(kt + 1);
+  // K-split over grid.z (few-pixel layers): this block owns the 64-deep steps [kbase, kbase + nk)
+  const int nk_all = (p.K + BK - 1) / BK, per_z = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int kbase = blockIdx.z * per_z, nk = min(nk_all, kbase + per_z) - kbase;
+  const int sw = swz(l16);                                            // tile row bases are multiples of 16
+  auto mma_step = [&](int buf) {
     const unsigned short* Xs = Xs0 + buf * BM * BK;
     const unsigned short* Ws = Ws0 + buf * BN * BK;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       const int co = ((ks * 4 + g) ^ sw) << 3;
       bf16x8 wf[NT], xf[MT];
 #pragma unroll
@@ -168,9 +171,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
-    if (more) store_step(buf ^ 1);
+  };
+  load_step(kbase, SA);
+  if (nk > 1) load_step(kbase + 1, SB);
+  store_step(0, SA);
+  if (nk > 2) load_step(kbase + 2, SA);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    mma_step(0);                                                      // step kt (LDS buffer 0)
+    if (kt + 1 < nk) store_step(1, SB);                               // step kt+1, loaded one step ago
+    if (kt + 3 < nk) load_step(kbase + kt + 3, SB);
     __syncthreads();
-    buf ^= 1;
+    if (kt + 1 >= nk) break;
+    mma_step(1);                                                      // step kt+1 (LDS buffer 1)
+    if (kt + 2 < nk) store_step(0, SA);
+    if (kt + 4 < nk) load_step(kbase + kt + 4, SA);
+    __syncthreads();
+  }
+  if (gridDim.z > 1) {                                                // partial sums -> this split's f32 slab (reduced in a fixed order by k_reduce_partials_bf16)
+    float* slab = p.partial + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wcol + j * 16 + g * 4;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wrow + i * 16 + l16;
+        if (m < p.M) *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
   }
 
   // D[row = channel 4g+r of the n-tile][col = pixel l16 of the m-tile]
@@ -280,12 +310,15 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ncs = (p.C + CS - 1) / CS;
-  load_slab(0);
+  // K-split over whole channel slabs: grid.y splits, each owns a contiguous slab range (the launcher guarantees none is empty)
+  const int ncs_all = (p.C + CS - 1) / CS;
+  const int per = (ncs_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int cs0 = blockIdx.y * per, ncs = min(ncs_all, cs0 + per);
+  load_slab(cs0);
   store_slab();
   __syncthreads();
   const int wsw = ((l16 >> 2) & 1) << 1;                              // weight rows of an n-tile start at a multiple of 16
-  for (int cs = 0; cs < ncs; ++cs) {
+  for (int cs = cs0; cs < ncs; ++cs) {
     const bool more = cs + 1 < ncs;
     if (more) load_slab(cs + 1);
 #pragma unroll
@@ -297,6 +330,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int hp = off + i * 16;
+        // (a wave-uniform "interior tile: skip the mask" branch was measured SLOWER, 243 vs 232 us on dense_e2: the scalar branches
+        // cut the unrolled tap loop into blocks the scheduler cannot interleave)
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ah + hp * CS + ((g ^ (((hp >> 2) & 1) << 1)) << 3));
         const uint4 u = __builtin_bit_cast(uint4, v);
         const unsigned keep = 0u - ((vmask[i] >> tap) & 1u);
@@ -310,6 +345,19 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
     __syncthreads();                                                  // every wave is past its last read of this slab
     if (more) { store_slab(); __syncthreads(); }
   }
+  if (gridDim.y > 1) {                                                // partial sums: plain f32 stores into this split's slab (no atomics: deterministic)
+    float* slab = p.partial + (size_t)blockIdx.y * p.M * 48;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = j * 16 + g * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wrow + i * 16 + l16;
+        if (m < p.M) *reinterpret_cast<float4*>(slab + (size_t)m * 48 + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = j * 16 + g * 4;
@@ -319,6 +367,19 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
       if (m < p.M)
         *reinterpret_cast<uint2*>(p.out + (long)m * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
     }
+  }
+}
+
+// out[m][n .. n+3] = bf16(sum_s partial[s][m][n .. n+3]) in a fixed order (s ascending): the reduction of the K-split
+__global__ __launch_bounds__(256) void k_reduce_partials_bf16(const float* __restrict__ partial, int split, long MN4, int n4, unsigned short* __restrict__ out, int ldc) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+    float4 a = *reinterpret_cast<const float4*>(partial + i * 4);
+    for (int s = 1; s < split; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(partial + ((size_t)s * MN4 + i) * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const long m = i / n4; const int n = (int)(i - m * n4) * 4;
+    *reinterpret_cast<uint2*>(out + m * ldc + n) = make_uint2(pack2(a.x, a.y), pack2(a.z, a.w));
   }
 }
 
@@ -472,20 +533,34 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   const long xb = ((long)(a.M - 1) * a.ldx + a.K) * 2, wb = ((long)(a.N - 1) * a.ldw + a.K) * 2;
   if (xb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("gemm_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.K * 4);
-  void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, 7);
+  void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, 7, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (double)a.M * a.N * (out_f32 ? 4 : 2));
   // tiles: 128 x 96 on big grids whose N is (nearly) a multiple of 96, 128 x 48 else; few pixels: 64 x 48 / 32 x 96 (more workgroups)
   const long t96 = (long)cdiv(a.M, 128) * cdiv(a.N, 96);
   const bool n96 = (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N;
-#define RDM_G(MT_, NT_, WM_, WN_)                                                                                                         \
+  // few pixels (decoder: 640 rows) and a long K: split K over grid.z so the chip is not left to ~80 workgroups
+  int split = 1;
+  const long small_blocks = (long)cdiv(a.M, 32) * cdiv(a.N, 96);
+  const int nk64 = cdiv(a.K, 64);
+  if (a.partial && !out_f32 && !a.bias && a.M <= 1024 && small_blocks < 256 && nk64 >= 8) {
+    split = (int)std::min<long>(std::min<long>(nk64 / 4, cdiv(512, small_blocks)), (long)(a.partial_floats / ((size_t)a.M * a.N)));
+    if (split < 1) split = 1;
+    split = cdiv(nk64, cdiv(nk64, split));                                // no empty split
+  }
+#define RDM_G(MT_, NT_, WM_, WN_, BK_)                                                                                                    \
   do {                                                                                                                                      \
-    dim3 grid(cdiv(a.N, NT_ * 16 * WN_), cdiv(a.M, MT_ * 16 * WM_));                                                                        \
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, true>), grid, dim3(256), 0, s, a);                                \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, false>), grid, dim3(256), 0, s, a);                                       \
+    dim3 grid(cdiv(a.N, NT_ * 16 * WN_), cdiv(a.M, MT_ * 16 * WM_), split);                                                                 \
+    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, true>), grid, dim3(256), 0, s, a);                           \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, false>), grid, dim3(256), 0, s, a);                                  \
   } while (0)
-  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2);
-  else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1);
-  else if (a.M > 1024) RDM_G(1, 3, 4, 1);                                // 64 x 48
-  else RDM_G(1, 3, 2, 2);                                                // 32 x 96
+  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64);
+  else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1, 64);
+  else if (a.M > 1024) RDM_G(1, 3, 4, 1, 64);                            // 64 x 48
+  else RDM_G(1, 3, 2, 2, 64);                                            // 32 x 96
+  if (split > 1) {
+    const long mn4 = (long)a.M * a.N / 4;
+    hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, a.N / 4,
+                       static_cast<unsigned short*>(a.out), a.ldc);
+  }
 #undef RDM_G
   profile_end(tk, s);
   RDM_LAUNCH_OK();
@@ -500,15 +575,36 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
   const long yb = ((long)(a.M - 1) * a.ldy + a.C) * 2, wb = (8L * a.wtap + 47L * a.ldw + a.C) * 2;
   if (yb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("conv3x3_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
   a.y_bytes = (unsigned)yb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.C * 4);
-  // 256-pixel tiles when that still gives >= 2 workgroups per CU, else 128, else 64
-  const int bm = (long)cdiv(a.M, 256) >= 512 ? 256 : (long)cdiv(a.M, 128) >= 128 ? 128 : 64;
+  // Tile and K-split.  Big pixel tiles stage the 27.6 KB weight slab once per 256 pixels (1.7x less L2 traffic per MFMA than
+  // 128-pixel tiles); short grids are filled by splitting the channel slabs over grid.y (>= 2 slabs per split), partial sums go to
+  // f32 slabs that one tiny launch reduces in a fixed order.  Target: 2-3 workgroups per CU.
+  const int bm = a.M >= 8192 ? 256 : a.M >= 4096 ? 128 : 64;
+  const int tiles = cdiv(a.M, bm), slabs = cdiv(a.C, 32);
+  int split = 1;
+  if (a.partial && tiles < 1024) {
+    // Cost model in units of one slab of one block: time ~ rounds x (slabs per block + 2 for prologue / epilogue) + the reduction
+    // pass (split x M x 48 x 8 bytes at ~3 TB/s).  `slots` workgroups are resident at once (256 CUs x 2 at 256-pixel tiles
+    // [186 VGPRs], x 3 below): wave quantisation matters - a grid of 1.06 x slots runs as long as one of 2 x slots.
+    const int slots = 256 * (bm == 256 ? 2 : 3);
+    const double t_slab = bm == 256 ? 2.5e-6 : bm == 128 ? 1.5e-6 : 1.0e-6;
+    const double red = (double)a.M * 384.0 / 3e12 / t_slab;
+    const long cap = std::min<long>(std::max(slabs / 2, 1), (long)(a.partial_floats / ((size_t)a.M * 48)));
+    double best = -1;
+    for (long sp = 1; sp <= cap; ++sp) {
+      const long per = cdiv(slabs, sp), spe = cdiv(slabs, per);           // effective split (no empty range)
+      const long blocks = (long)tiles * spe, rounds = (blocks + slots - 1) / slots;
+      const double cost = (double)rounds * (double)(per + 2) + (spe > 1 ? spe * red : 0.0);
+      if (best < 0 || cost < best * 0.97) { best = cost; split = (int)spe; }
+    }
+  }
+  a.split = split;
   const int halo = bm + 2 * (a.W + 1);
   const int hl = cdiv(halo * 4, 256);
   RDM_CHECK_ARG(hl <= 16, "conv3x3_bf16: rows of %d pixels need a halo of %d pixels (> 1024)", a.W, halo);
   const size_t ldsb = ((size_t)((halo + 7) & ~7) * 32 + 9 * 48 * 32) * 2;
   RDM_CHECK_ARG(ldsb <= 160 * 1024, "conv3x3_bf16: halo tile of %zu bytes exceeds the 160 KB LDS", ldsb);
-  void* tk = profile_begin(s, 2.0 * a.M * 48.0 * a.C * 9.0, 8);
-  dim3 grid(cdiv(a.M, bm));
+  void* tk = profile_begin(s, 2.0 * a.M * 48.0 * a.C * 9.0, 8, 2.0 * ((double)a.M * a.C + 9.0 * 48 * a.C + (double)a.M * 48));
+  dim3 grid(tiles, split);
 #define RDM_C3(MT_, HL_)                                                                                                                  \
   do {                                                                                                                                     \
     if (ldsb > 65536) RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<MT_, HL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
@@ -522,6 +618,10 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
   if (bm == 256) RDM_C3M(4); else if (bm == 128) RDM_C3M(2); else RDM_C3M(1);
 #undef RDM_C3M
 #undef RDM_C3
+  if (split > 1) {
+    const long mn4 = (long)a.M * 12;
+    hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, 12, a.out, a.ldc);
+  }
   profile_end(tk, s);
   RDM_LAUNCH_OK();
   return 0;

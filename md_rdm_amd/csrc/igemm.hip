@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
 // launch stream around every conv kernel; read back (and summed) by rdm_profile_read().
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; double bytes; };
 struct Prof {
   bool on = false;
   std::vector<ProfRec> recs;
@@ -851,9 +851,9 @@ struct Prof {
   }
 } g_prof;
 struct ProfScope {
-  hipStream_t s; double flops; hipEvent_t a{}, b{}; bool on; int kind = 0;
+  hipStream_t s; double flops; hipEvent_t a{}, b{}; bool on; int kind = 0; double bytes = 0;
   ProfScope(hipStream_t s_, double f) : s(s_), flops(f), on(g_prof.on) { if (on) { a = g_prof.get(); b = g_prof.get(); hipEventRecord(a, s); } }
-  ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind}); } }
+  ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind, bytes}); } }
 };
 // per-kernel breakdown of the last profile_read()
 constexpr int PROF_KINDS = 9;
@@ -861,17 +861,19 @@ const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
     "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel",
     "gemm_bf16_kernel (1x1 forward, bf16 MFMA)", "conv3x3_bf16_kernel (3x3 forward, bf16 MFMA)"};
-double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS];
+double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS], g_kind_bytes[PROF_KINDS];
 int g_kind_n[PROF_KINDS];
 }  // namespace
 
 // the same bracket for launchers outside this file (bf16.hip)
-void* profile_begin(hipStream_t s, double flops, int kind) {
+void* profile_begin(hipStream_t s, double flops, int kind, double bytes) {
   if (!g_prof.on) return nullptr;
   ProfScope* t = new ProfScope(s, flops);
   t->kind = kind;
+  t->bytes = bytes;
   return t;
 }
+double profile_kind_bytes(int kind) { return kind >= 0 && kind < PROF_KINDS ? g_kind_bytes[kind] : -1.0; }
 void profile_end(void* ticket, hipStream_t) { delete static_cast<ProfScope*>(ticket); }
 
 static hipEvent_t g_prof_base = nullptr;
@@ -890,7 +892,7 @@ int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches)
   double t = 0, f = 0;
   std::vector<std::pair<float, float>> iv;
   iv.reserve(g_prof.recs.size());
-  for (int k = 0; k < PROF_KINDS; ++k) { g_kind_ms[k] = 0; g_kind_flops[k] = 0; g_kind_n[k] = 0; }
+  for (int k = 0; k < PROF_KINDS; ++k) { g_kind_ms[k] = 0; g_kind_flops[k] = 0; g_kind_n[k] = 0; g_kind_bytes[k] = 0; }
   for (auto& r : g_prof.recs) {
     RDM_HIP_OK(hipEventSynchronize(r.b));
     float a0 = 0, b0 = 0;
@@ -898,7 +900,7 @@ int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches)
     RDM_HIP_OK(hipEventElapsedTime(&b0, g_prof_base, r.b));
     iv.emplace_back(a0, b0);
     t += b0 - a0; f += r.flops;
-    g_kind_ms[r.kind] += b0 - a0; g_kind_flops[r.kind] += r.flops; g_kind_n[r.kind] += 1;
+    g_kind_ms[r.kind] += b0 - a0; g_kind_flops[r.kind] += r.flops; g_kind_n[r.kind] += 1; g_kind_bytes[r.kind] += r.bytes;
     g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
   }
   std::sort(iv.begin(), iv.end());

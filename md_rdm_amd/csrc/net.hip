@@ -143,7 +143,7 @@ struct NetImpl {
   struct Bf16Layer { size_t w1, w3, bn1, bn2; };
   std::vector<Bf16Layer> bfl[4];
   size_t bf_wt[3], bf_tbn[3], bf_stem_w, bf_head_w, bf_wtotal = 0;
-  size_t bf_patches, bf_e1, bf_blk[4], bf_Y, bf_P[3], bf_logits, bf_total = 0;
+  size_t bf_patches, bf_e1, bf_blk[4], bf_Y, bf_P[3], bf_logits, bf_partial, bf_partial_floats, bf_total = 0;
   double bf_bytes = 0;      // algorithmic HBM bytes of one bf16 forward (every activation written once, read by its consumers once; weights once)
   void plan_bf16() {
     Bump w;
@@ -175,6 +175,13 @@ struct NetImpl {
     bf_Y = a.take<unsigned short>(maxY);
     for (int t = 0; t < 3; ++t) bf_P[t] = a.take<unsigned short>((size_t)bg[t + 1].M * kTrans[t].cin);
     bf_logits = a.take<float>((size_t)bg[3].M * 192);
+    bf_partial_floats = 0;                                        // K-split partial sums of the 3x3 convs: up to 24 slabs of [M][48] f32
+    for (int b = 0; b < 4; ++b) {
+      const int split = std::min(std::max(cdiv(bg[b].cb, 32) / 2, 1), 16);       // the launcher sizes the split to what it is given
+      bf_partial_floats = std::max(bf_partial_floats, (size_t)split * bg[b].M * GROWTH);
+    }
+    bf_partial_floats = std::max(bf_partial_floats, (size_t)8 * bg[3].M * bg[3].cb);      // K-split of the decoder's 1x1 convs
+    bf_partial = a.take<float>(bf_partial_floats);
     bf_total = (a.off + 255) & ~(size_t)255;
     // algorithmic traffic: x (f32) + patches w+r + e1 w+r + per layer [prefix read + Y write + Y read + 48-slice write] + transitions + head
     double by = (double)B * 3 * H0 * W0 * 4 + 2.0 * M1 * 160 * 2 + 2.0 * M1 * 96 * 2 + (double)bg[0].M * 96 * 2;
@@ -738,11 +745,13 @@ int rdm_net_forward_bf16(rdm_net* net, const float* x, void* const* T, const voi
       a.X = blk; a.ldx = g.ctot; a.K = cin; a.scale = bn1; a.shift = bn1 + cin;
       a.W = at<char>(wb, W.w1); a.ldw = cin;
       a.out = at<char>(ws, n.bf_Y); a.ldc = g.cb; a.M = g.M; a.N = g.cb;
+      a.partial = at<float>(ws, n.bf_partial); a.partial_floats = n.bf_partial_floats;
       if ((rc = launch_gemm_bf16(a, false, s))) return rc;
       Conv3Bf16Args c{};                                     // BN-ReLU -> 3x3 (cb -> 48), written in place behind the block's channels
       c.Y = at<char>(ws, n.bf_Y); c.ldy = g.cb; c.C = g.cb; c.scale = bn2; c.shift = bn2 + g.cb;
       c.Wt = at<char>(wb, W.w3); c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
       c.out = blk + cin; c.ldc = g.ctot; c.B = n.B; c.H = g.H; c.W = g.W; c.M = g.M;
+      c.partial = at<float>(ws, n.bf_partial); c.partial_floats = n.bf_partial_floats;
       if ((rc = launch_conv3x3_bf16(c, s))) return rc;
     }
     if (b < 3) {

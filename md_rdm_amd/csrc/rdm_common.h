@@ -85,7 +85,8 @@ int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 int pick_split_k(long tiles, long kslabs, int slots);
 void profile_enable(bool on);
-void* profile_begin(hipStream_t s, double flops, int kind);     // event bracket around one launch (no-op unless profiling is enabled)
+void* profile_begin(hipStream_t s, double flops, int kind, double bytes = 0);   // event bracket around one launch (no-op unless profiling is enabled)
+double profile_kind_bytes(int kind);
 void profile_end(void* ticket, hipStream_t s);
 int profile_read(double* ms_sum, double* ms_union, double* flops, int* launches);
 int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int* launches);

@@ -70,8 +70,8 @@ def validation_step(model, x, y):
 
 
 class FusedAdamW:
-    """torch.optim.AdamW(lr) semantics (module.py:41) as ONE launch over the model's flat parameter /
-    gradient buffers + a tiny torch step for the 4 Weights scalars."""
+    """torch.optim.AdamW(lr) semantics (module.py:41) as one launch per contiguous TRAINABLE range of the model's flat parameter /
+    gradient buffers (2 for the reference's live graph) + a tiny torch step for the 4 Weights scalars."""
 
     def __init__(self, model: DepthEstimationNet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
@@ -115,6 +115,7 @@ class FusedAdamW:
             _lib.check(L.rdm_adamw_fused(off(flat.data_ptr() + 4 * a), off(gflat.data_ptr() + 4 * a), off(self.m.data_ptr() + 4 * a),
                                          off(self.v.data_ptr() + 4 * a), b - a, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                          self.step_count, float(grad_scale), st))
+        self.model.mark_weights_changed()                         # derived bf16 copies are stale now
         self.small.step()
 
     def state_dict(self):
