@@ -210,6 +210,14 @@ int rdm_net_backward(rdm_net* net, const float* dlogits_nchw, void* const* tenso
                      size_t workspace_bytes, int32_t first_segment, int32_t last_segment, rdm_stream_t stream);
 /* (first,last) tensor index range whose gradients segment `seg` produces */
 int rdm_net_segment_range(int32_t seg, int32_t* first_tensor, int32_t* last_tensor);
+/* The same backward at bucket granularity: the segments cut into STAGES of consecutive dense layers holding ~25 MB of gradients each
+ * (the bucket size of the DistributedDataParallel the reference trains under, train.py:55), so the caller can start an all-reduce
+ * every few layers and the last exchange is small.  Stages must be run in order 0 .. rdm_net_num_backward_stages()-1; the tensors
+ * of stage k form the contiguous index range rdm_net_backward_stage_range gives (stages run from the LAST registered tensor backwards). */
+int rdm_net_num_backward_stages(void);
+int rdm_net_backward_stage_range(int32_t stage, int32_t* first_tensor, int32_t* last_tensor);
+int rdm_net_backward_stage(rdm_net* net, const float* dlogits_nchw, void* const* tensors, void* const* grads, void* workspace,
+                           size_t workspace_bytes, int32_t stage, rdm_stream_t stream);
 /* test/debug access to the workspace layout: byte offset + float count of a named internal buffer
  * ("blk0".."blk3" block activations NHWC, "G0".."G3" their gradients, "logits", "Y<b>_<i>" bottlenecks ...) */
 int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, int64_t* numel);

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "rdm_net_forward_bf16": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, sz, vp, vp]),
     "rdm_net_backward": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, sz, i32, i32, vp]),
     "rdm_net_segment_range": (C.c_int, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    "rdm_net_num_backward_stages": (C.c_int, []),
+    "rdm_net_backward_stage_range": (C.c_int, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    "rdm_net_backward_stage": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, sz, i32, vp]),
     "rdm_net_buffer": (C.c_int, [vp, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]),
     "rdm_net_forward_flops": (f64, [vp]),
     "rdm_net_backward_flops": (f64, [vp]),

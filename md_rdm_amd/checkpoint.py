@@ -1,25 +1,100 @@
 """Checkpoint wire format: the reference saves through Lightning's ModelCheckpoint
 (train.py:41-47), whose ``state_dict`` holds the network under the attribute name of the LightningModule
 (``self.model``, network/module.py:32) - i.e. every key carries a ``model.`` prefix.  The 968 keys underneath
-are identical to ours, so trained weights interchange in both directions."""
+are identical to ours, so trained weights interchange in both directions.
+
+A genuine Lightning 1.1.x ``.ckpt`` is a pickle that also carries non-tensor objects: ``hyper_parameters`` (an ``AttributeDict``
+from ``save_hyperparameters``), ``callbacks`` keyed by the ``ModelCheckpoint`` CLASS, ``optimizer_states``, ``lr_schedulers``.
+torch >= 2.6 refuses those under ``weights_only=True``; only ``state_dict`` is wanted here, so the file is read with an unpickler
+that resolves every non-torch global to an inert stand-in instead of importing (or requiring) pytorch_lightning: nothing but
+tensors and containers is ever instantiated from the file.
+
+Training state written by ``md_rdm_amd.train`` (``optimizer_states``, ``lr_schedulers``, ``epoch``, ``global_step``) uses the same
+top-level keys as Lightning; the optimiser entry is this stack's FusedAdamW state (flat moments), which Lightning could not
+consume - resuming a reference run here restores the WEIGHTS, resuming one of our runs restores everything."""
+import io
+import pickle
+
 import torch
 
 PREFIX = "model."
 
 
-def to_lightning(model, extra=None):
-    """{'state_dict': {'model.<key>': tensor}, ...} as a Lightning 1.1.x .ckpt would hold it."""
+def to_lightning(model, extra=None, optimizer=None, scheduler=None):
+    """{'state_dict': {'model.<key>': tensor}, ...} as a Lightning 1.1.x .ckpt would hold it (+ our optimiser / scheduler state)."""
     sd = {PREFIX + k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     ckpt = {"state_dict": sd, "pytorch-lightning_version": "1.1.7", "epoch": 0, "global_step": 0}
+    if optimizer is not None:
+        ckpt["optimizer_states"] = [optimizer.state_dict()]
+    if scheduler is not None:
+        ckpt["lr_schedulers"] = [scheduler.state_dict()]
     ckpt.update(extra or {})
     return ckpt
 
 
-def from_lightning(model, ckpt, strict=True):
-    """Load a Lightning checkpoint (dict or path) or a bare state_dict into a DepthEstimationNet."""
+class _Inert:
+    """Stand-in for any class a foreign checkpoint references (AttributeDict, ModelCheckpoint, Namespace ...): swallows construction
+    and state, never executes foreign code."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        pass
+
+    def __setitem__(self, k, v):
+        pass
+
+    def __reduce_ex__(self, proto):
+        return (_Inert, ())
+
+
+class _TensorOnlyUnpickler(pickle.Unpickler):
+    _ALLOWED = ("torch", "collections", "numpy", "builtins", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in self._ALLOWED:
+            return super().find_class(module, name)
+        return _Inert
+
+
+class _TensorOnlyPickle:
+    """pickle_module for torch.load: real torch / container types, inert stand-ins for everything else."""
+    __name__ = "tensor_only_pickle"
+    Unpickler = _TensorOnlyUnpickler
+    load = staticmethod(lambda f, **k: _TensorOnlyUnpickler(f, **k).load())
+    loads = staticmethod(lambda b, **k: _TensorOnlyUnpickler(io.BytesIO(b), **k).load())
+    dump, dumps, Pickler = pickle.dump, pickle.dumps, pickle.Pickler
+
+
+def load_checkpoint_file(path):
+    """The checkpoint dict of ``path``: first the safe tensor-only loader, then (foreign classes present) the stand-in unpickler."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError):
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TensorOnlyPickle)
+
+
+def from_lightning(model, ckpt, strict=True, optimizer=None, scheduler=None):
+    """Load a Lightning checkpoint (dict or path) or a bare state_dict into a DepthEstimationNet; returns (load result, ckpt dict).
+    ``optimizer`` / ``scheduler``: restored too when the checkpoint carries OUR training state (see module docstring)."""
     if isinstance(ckpt, (str, bytes)):
-        ckpt = torch.load(ckpt, map_location="cpu")
+        ckpt = load_checkpoint_file(ckpt)
     sd = ckpt.get("state_dict", ckpt)
     if any(k.startswith(PREFIX) for k in sd):
         sd = {k[len(PREFIX):]: v for k, v in sd.items() if k.startswith(PREFIX)}
-    return model.load_state_dict(sd, strict=strict)
+    res = model.load_state_dict(sd, strict=strict)
+    return res, ckpt
+
+
+def restore_training_state(ckpt, optimizer, scheduler=None):
+    """Optimiser moments / step / lr and the plateau scheduler from a checkpoint written by md_rdm_amd.train; False when the file
+    holds none (a reference checkpoint: weights only)."""
+    st = ckpt.get("optimizer_states") if isinstance(ckpt, dict) else None
+    if not st or not isinstance(st[0], dict) or "exp_avg" not in st[0]:
+        return False
+    optimizer.load_state_dict(st[0])
+    ls = ckpt.get("lr_schedulers")
+    if scheduler is not None and ls and isinstance(ls[0], dict) and "best" in ls[0]:
+        scheduler.load_state_dict(ls[0])
+    return True

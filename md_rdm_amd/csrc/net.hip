@@ -42,6 +42,40 @@ struct Registry {
   BnIdx trans_bn[3]; int trans_conv[3];
   int conv1_w, conv1_b, conv2_w, conv2_b;
   int seg_first[4], seg_last[4];
+  // backward STAGES: the 4 segments cut into runs of dense layers holding >= ~6.5 M gradient floats (~25 MB, the DDP bucket size
+  // the reference's Lightning DDP uses) so a gradient exchange can start every few layers and the LAST one is small
+  struct Stage { int seg, block, i_hi, i_lo; bool first_of_seg, last_of_seg; int first_t, last_t; };
+  std::vector<Stage> stages;
+  long layer_floats(int b, int i) const {
+    const LayerIdx& L = layers[b][i];
+    return t[L.bn1.w].numel * 2 + t[L.conv1].numel + t[L.bn2.w].numel * 2 + t[L.conv2].numel;
+  }
+  void build_stages() {
+    const long kBucket = 6500000;
+    for (int seg = 0; seg < 4; ++seg) {
+      const int b = 3 - seg, nl = (int)layers[b].size();
+      int hi = nl - 1;
+      const size_t first_stage = stages.size();
+      while (hi >= 0) {
+        long acc = 0;
+        int lo = hi;
+        for (;;) {
+          acc += layer_floats(b, lo);
+          if (acc >= kBucket || lo == 0) break;
+          --lo;
+        }
+        if (lo > 0 && lo <= 1) lo = 0;                           // do not leave a one-layer tail
+        Stage st{seg, b, hi, lo, false, false, layers[b][lo].bn1.w, layers[b][hi].conv2};
+        stages.push_back(st);
+        hi = lo - 1;
+      }
+      Stage& f = stages[first_stage];
+      Stage& l = stages.back();
+      f.first_of_seg = true; l.last_of_seg = true;
+      f.last_t = seg_last[seg];                                  // head (seg 0) / the transition after the block (segs 1..3) run first
+      l.first_t = seg_first[seg];                                // the stem's tensors ride with the last stage of segment 3
+    }
+  }
   int add(const std::string& n, int64_t numel, int p) { t.push_back({n, numel, p}); return (int)t.size() - 1; }
   BnIdx add_bn(const std::string& p, int c) {
     BnIdx b;
@@ -86,6 +120,7 @@ struct Registry {
     seg_first[1] = e4_first; seg_last[1] = d_first - 1;
     seg_first[2] = e3_first; seg_last[2] = e4_first - 1;
     seg_first[3] = 0; seg_last[3] = e3_first - 1;
+    build_stages();
   }
 };
 const Registry& reg() { static Registry r; return r; }
@@ -412,7 +447,7 @@ int zero_f32(float* p, size_t n, hipStream_t s) {
   return 0;
 }
 
-int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
+int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
   const BlockGeom& g = n.bg[b];
   const int training = n.training_saved;
   float* blk = at<float>(ws, n.blk[b]);
@@ -421,7 +456,7 @@ int backward_block(NetImpl& n, int b, void* ws, void* const* T, void* const* Gr,
   int rc;
   if ((rc = n.ensure_side())) return rc;
   hipStream_t side = n.side;
-  for (int i = kBlocks[b].layers - 1; i >= 0; --i) {
+  for (int i = i_hi; i >= i_lo; --i) {
     const LayerIdx& L = reg().layers[b][i];
     const LayerWs& W = n.lws[b][i];
     const int cin = kBlocks[b].cin + i * GROWTH, cb = g.cb;
@@ -778,6 +813,95 @@ int rdm_net_forward_bf16(rdm_net* net, const float* x, void* const* T, const voi
   return RDM_OK;
 }
 
+static int backward_head(NetImpl& n, const float* dlogits, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
+  int rc;
+  RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.bwd_stats_begin), 0, n.bwd_stats_end - n.bwd_stats_begin, s));
+  const BlockGeom& g = n.bg[3];
+  float* dL = at<float>(ws, n.dL);
+  if ((rc = launch_nchw_to_nhwc(dlogits, dL, 192, n.B, 180, g.H * g.W, s))) return rc;
+  const int wi = reg().conv2_w, bi = reg().conv2_b;
+  if (Gr[bi]) {
+    double* t64 = at<double>(ws, n.tmp64);
+    RDM_HIP_OK(hipMemsetAsync(t64, 0, 512 * sizeof(double), s));
+    if ((rc = launch_colstats(dL, 192, g.M, 180, t64, nullptr, s))) return rc;
+    if ((rc = launch_f64_to_f32(t64, F(Gr, bi), 180, s))) return rc;
+  }
+  if (Gr[wi]) {
+    if ((rc = zero_f32(F(Gr, wi), (size_t)180 * 2208, s))) return rc;
+    WgradArgs w{};
+    w.g = geom1x1(n.B, g.H, g.W);
+    w.G = dL; w.ldg = 192; w.N = 180;
+    w.Xs = at<float>(ws, n.blk[3]); w.ldx = g.ctot; w.C = g.ctot;
+    w.dW = F(Gr, wi); w.wtap = 0; w.ldw = g.ctot;
+    if ((rc = launch_conv_wgrad(w, s))) return rc;
+  }
+  // dgrad needs a contracted extent that is a multiple of 16: 180 -> 192 zero rows
+  if ((rc = launch_pack_w(F(T, wi), at<float>(ws, n.w2pad), 180, 2208, 1, 192, s))) return rc;
+  FwdArgs d{};
+  d.g = geom1x1(n.B, g.H, g.W);
+  d.A = dL; d.lda = 192; d.C = 192;
+  d.Wt = at<float>(ws, n.w2pad); d.wtap = 0; d.ldw = 2208;
+  d.out = at<float>(ws, n.G[3]); d.ldc = g.ctot; d.M = g.M; d.N = g.ctot;
+  if ((rc = launch_conv_fwd(d, true, EPI_STORE, s)) < 0) return rc;
+  // d_1.conv1 is constructed but unused for id 1 (RDM_Net.py:156-157): no gradient
+  return 0;
+}
+
+static int backward_stem(NetImpl& n, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
+  // stem: max-pool backward, bias gradient, weight gradient (no gradient into the image)
+  int rc;
+  float* gE1 = at<float>(ws, n.gE1);
+  if ((rc = launch_maxpool3s2_bwd(at<float>(ws, n.G[0]), n.bg[0].ctot, at<unsigned char>(ws, n.argmax), gE1, n.B, n.H1, n.W1, 96, s))) return rc;
+  if (Gr[reg().stem_b]) {
+    double* t64 = at<double>(ws, n.tmp64);
+    RDM_HIP_OK(hipMemsetAsync(t64, 0, 512 * sizeof(double), s));
+    if ((rc = launch_colstats(gE1, 96, n.M1, 96, t64, nullptr, s))) return rc;
+    if ((rc = launch_f64_to_f32(t64, F(Gr, reg().stem_b), 96, s))) return rc;
+  }
+  if (Gr[reg().stem_w]) {
+    float* dWs = at<float>(ws, n.dWstem);
+    if ((rc = zero_f32(dWs, 96 * 160, s))) return rc;
+    WgradArgs w{};
+    w.g = ConvGeom{n.B, n.H1, n.W1, n.H1, n.W1, 1, 1, 1, 1, 0, 0, 1};
+    w.G = gE1; w.ldg = 96; w.N = 96;
+    w.Xs = at<float>(ws, n.patches); w.ldx = 160; w.C = 160;
+    w.dW = dWs; w.wtap = 0; w.ldw = 160;
+    if ((rc = launch_conv_wgrad(w, s))) return rc;
+    RDM_HIP_OK(hipMemcpy2DAsync(Gr[reg().stem_w], 147 * sizeof(float), dWs, 160 * sizeof(float), 147 * sizeof(float), 96, hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+static int backward_stage(NetImpl& n, int stage, const float* dlogits, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
+  const Registry::Stage& st = reg().stages[stage];
+  int rc;
+  if (st.first_of_seg) {
+    if (st.seg == 0) { if ((rc = backward_head(n, dlogits, ws, T, Gr, s))) return rc; }
+    else if ((rc = backward_transition(n, st.block, ws, T, Gr, s))) return rc;          // seg 1 -> trans_e4 (t = 2) feeding dense_e4 (b = 2), ...
+  }
+  if ((rc = backward_block(n, st.block, st.i_hi, st.i_lo, ws, T, Gr, s))) return rc;
+  if (st.last_of_seg && st.seg == 3 && (rc = backward_stem(n, ws, T, Gr, s))) return rc;
+  return 0;
+}
+
+int rdm_net_num_backward_stages(void) { return (int)reg().stages.size(); }
+
+int rdm_net_backward_stage_range(int32_t stage, int32_t* first, int32_t* last) {
+  RDM_CHECK_ARG(stage >= 0 && stage < (int)reg().stages.size() && first && last, "stage must be 0..%d", (int)reg().stages.size() - 1);
+  *first = reg().stages[stage].first_t; *last = reg().stages[stage].last_t;
+  return RDM_OK;
+}
+
+int rdm_net_backward_stage(rdm_net* net, const float* dlogits, void* const* T, void* const* Gr, void* ws, size_t ws_bytes, int32_t stage,
+                           rdm_stream_t stream) {
+  RDM_CHECK_ARG(net && T && Gr && ws, "NULL argument");
+  RDM_CHECK_ARG(stage >= 0 && stage < (int)reg().stages.size(), "stage must be 0..%d", (int)reg().stages.size() - 1);
+  RDM_CHECK_ARG(stage != 0 || dlogits != nullptr, "dlogits is NULL");
+  NetImpl& n = *reinterpret_cast<NetImpl*>(net);
+  if (ws_bytes < n.total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  return backward_stage(n, stage, dlogits, ws, T, Gr, stream);
+}
+
 int rdm_net_backward(rdm_net* net, const float* dlogits, void* const* T, void* const* Gr, void* ws, size_t ws_bytes, int32_t first_seg,
                      int32_t last_seg, rdm_stream_t stream) {
   RDM_CHECK_ARG(net && T && Gr && ws, "NULL argument");
@@ -785,68 +909,10 @@ int rdm_net_backward(rdm_net* net, const float* dlogits, void* const* T, void* c
   RDM_CHECK_ARG(first_seg != 0 || dlogits != nullptr, "dlogits is NULL");
   NetImpl& n = *reinterpret_cast<NetImpl*>(net);
   if (ws_bytes < n.total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
-  hipStream_t s = stream;
-  int rc;
-  for (int seg = first_seg; seg <= last_seg; ++seg) {
-    if (seg == 0) {
-      RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.bwd_stats_begin), 0, n.bwd_stats_end - n.bwd_stats_begin, s));
-      const BlockGeom& g = n.bg[3];
-      float* dL = at<float>(ws, n.dL);
-      if ((rc = launch_nchw_to_nhwc(dlogits, dL, 192, n.B, 180, g.H * g.W, s))) return rc;
-      const int wi = reg().conv2_w, bi = reg().conv2_b;
-      if (Gr[bi]) {
-        double* t64 = at<double>(ws, n.tmp64);
-        RDM_HIP_OK(hipMemsetAsync(t64, 0, 512 * sizeof(double), s));
-        if ((rc = launch_colstats(dL, 192, g.M, 180, t64, nullptr, s))) return rc;
-        if ((rc = launch_f64_to_f32(t64, F(Gr, bi), 180, s))) return rc;
-      }
-      if (Gr[wi]) {
-        if ((rc = zero_f32(F(Gr, wi), (size_t)180 * 2208, s))) return rc;
-        WgradArgs w{};
-        w.g = geom1x1(n.B, g.H, g.W);
-        w.G = dL; w.ldg = 192; w.N = 180;
-        w.Xs = at<float>(ws, n.blk[3]); w.ldx = g.ctot; w.C = g.ctot;
-        w.dW = F(Gr, wi); w.wtap = 0; w.ldw = g.ctot;
-        if ((rc = launch_conv_wgrad(w, s))) return rc;
-      }
-      // dgrad needs a contracted extent that is a multiple of 16: 180 -> 192 zero rows
-      if ((rc = launch_pack_w(F(T, wi), at<float>(ws, n.w2pad), 180, 2208, 1, 192, s))) return rc;
-      FwdArgs d{};
-      d.g = geom1x1(n.B, g.H, g.W);
-      d.A = dL; d.lda = 192; d.C = 192;
-      d.Wt = at<float>(ws, n.w2pad); d.wtap = 0; d.ldw = 2208;
-      d.out = at<float>(ws, n.G[3]); d.ldc = g.ctot; d.M = g.M; d.N = g.ctot;
-      if ((rc = launch_conv_fwd(d, true, EPI_STORE, s)) < 0) return rc;
-      if ((rc = backward_block(n, 3, ws, T, Gr, s))) return rc;
-      // d_1.conv1 is constructed but unused for id 1 (RDM_Net.py:156-157): no gradient
-    } else {
-      const int t = 3 - seg;          // seg 1 -> trans_e4 (t=2) + dense_e4 (b=2), ...
-      if ((rc = backward_transition(n, t, ws, T, Gr, s))) return rc;
-      if ((rc = backward_block(n, t, ws, T, Gr, s))) return rc;
-      if (seg == 3) {
-        // stem: max-pool backward, bias gradient, weight gradient (no gradient into the image)
-        float* gE1 = at<float>(ws, n.gE1);
-        if ((rc = launch_maxpool3s2_bwd(at<float>(ws, n.G[0]), n.bg[0].ctot, at<unsigned char>(ws, n.argmax), gE1, n.B, n.H1, n.W1, 96, s))) return rc;
-        if (Gr[reg().stem_b]) {
-          double* t64 = at<double>(ws, n.tmp64);
-          RDM_HIP_OK(hipMemsetAsync(t64, 0, 512 * sizeof(double), s));
-          if ((rc = launch_colstats(gE1, 96, n.M1, 96, t64, nullptr, s))) return rc;
-          if ((rc = launch_f64_to_f32(t64, F(Gr, reg().stem_b), 96, s))) return rc;
-        }
-        if (Gr[reg().stem_w]) {
-          float* dWs = at<float>(ws, n.dWstem);
-          if ((rc = zero_f32(dWs, 96 * 160, s))) return rc;
-          WgradArgs w{};
-          w.g = ConvGeom{n.B, n.H1, n.W1, n.H1, n.W1, 1, 1, 1, 1, 0, 0, 1};
-          w.G = gE1; w.ldg = 96; w.N = 96;
-          w.Xs = at<float>(ws, n.patches); w.ldx = 160; w.C = 160;
-          w.dW = dWs; w.wtap = 0; w.ldw = 160;
-          if ((rc = launch_conv_wgrad(w, s))) return rc;
-          RDM_HIP_OK(hipMemcpy2DAsync(Gr[reg().stem_w], 147 * sizeof(float), dWs, 160 * sizeof(float), 147 * sizeof(float), 96,
-                                      hipMemcpyDeviceToDevice, s));
-        }
-      }
-    }
+  for (int st = 0; st < (int)reg().stages.size(); ++st) {
+    const int seg = reg().stages[st].seg;
+    if (seg < first_seg || seg > last_seg) continue;
+    if (int rc = backward_stage(n, st, dlogits, ws, T, Gr, stream)) return rc;
   }
   return RDM_OK;
 }

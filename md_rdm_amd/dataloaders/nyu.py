@@ -190,8 +190,14 @@ class PrefetchLoader:
     """Iterate (x, y) training / validation batches: a reader thread fills pinned staging buffers one batch ahead, the
     H2D copies run on a dedicated copy stream, and the augmentation kernels run on the consumer's stream after an event wait."""
 
-    def __init__(self, dataset, batch_size, shuffle=None, seed=0, device="cuda", drop_last=True, rank=0, world=1):
+    def __init__(self, dataset, batch_size, shuffle=None, seed=0, device="cuda", drop_last=True, rank=0, world=1, workers=0):
+        """``workers`` (the reference's ``--worker``, module.py:19-27 DataLoader(num_workers=...)): threads that decode the raw samples of a
+        batch in parallel (h5 / npz reads release the GIL); 0 = decode in the reader thread.  The augmentation itself runs on the GPU."""
         self.ds, self.bs, self.device = dataset, batch_size, torch.device(device)
+        self.pool = None
+        if workers and workers > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=int(workers))
         self.train = dataset.split == "train"
         self.shuffle = self.train if shuffle is None else shuffle
         self.rng = np.random.default_rng(seed + rank)
@@ -205,7 +211,7 @@ class PrefetchLoader:
         return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
 
     def _read(self, idx):
-        raws = [self.ds.get_raw(i) for i in idx]
+        raws = list(self.pool.map(self.ds.get_raw, idx)) if self.pool is not None else [self.ds.get_raw(i) for i in idx]
         H, W = raws[0][1].shape
         rgb = torch.empty(len(idx), H, W, 3, dtype=torch.uint8).pin_memory()
         dep = torch.empty(len(idx), H, W, dtype=torch.float32).pin_memory()

@@ -133,3 +133,57 @@ class FusedAdamW:
         self.small.load_state_dict(sd["small"])
         for g in self.small.param_groups:
             g["lr"] = self.lr
+
+
+def find_learning_rate(model, opt, batches, min_lr=1e-8, max_lr=1.0, num_training=100, early_stop_threshold=4.0, beta=0.98, sync=None):
+    """The learning-rate range test the reference runs for ``--find_learning_rate`` (train.py:74-80: ``trainer.tuner.lr_find(module)``
+    + ``lr_finder.suggestion()``; pytorch_lightning 1.1.7 defaults, third party): ``num_training`` steps with the learning rate swept
+    exponentially from ``min_lr`` to ``max_lr``, an exponentially smoothed (beta 0.98, bias-corrected) loss per step, early stop once
+    it exceeds ``early_stop_threshold`` x the best; the suggestion is the rate at the steepest descent of the smoothed loss
+    (``numpy.gradient(...).argmin()``, skipping the first 10 and the last point).  Weights, BatchNorm buffers and optimiser state are
+    restored afterwards, as Lightning does.  Returns (suggested_lr or None, lrs, smoothed losses)."""
+    import numpy as np
+    flat = model._flat[0]
+    saved = (flat.detach().clone(), {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("weight_layer.") or "running_" in k or "num_batches" in k},
+             opt.state_dict())
+    lrs, losses, avg, best = [], [], 0.0, None
+    it = iter(batches)
+    for i in range(num_training):
+        try:
+            x, y = next(it)
+        except StopIteration:
+            it = iter(batches)
+            x, y = next(it)
+        lr = min_lr * (max_lr / min_lr) ** (i / max(num_training - 1, 1))
+        opt.lr = lr
+        for g in opt.small.param_groups:
+            g["lr"] = lr
+        opt.zero_grad()
+        loss, _ = training_step(model, x, y)
+        loss.backward()
+        opt.step(grad_scale=sync.finish() if sync is not None else 1.0)
+        cur = float(loss.item())
+        avg = beta * avg + (1 - beta) * cur
+        smooth = avg / (1 - beta ** (i + 1))
+        lrs.append(lr)
+        losses.append(smooth)
+        if not np.isfinite(smooth) or (i > 0 and best is not None and smooth > early_stop_threshold * best):
+            break
+        if best is None or smooth < best:
+            best = smooth
+    with torch.no_grad():                                           # restore: the sweep must not leave a trace
+        flat.copy_(saved[0])
+        sd = model.state_dict()
+        for k, v in saved[1].items():
+            sd[k].copy_(v)
+    opt.load_state_dict(saved[2])
+    if opt.m is not None and saved[2]["exp_avg"] is None:
+        opt.m.zero_()
+        opt.v.zero_()
+    model.mark_weights_changed()
+    skip_begin, skip_end = 10, 1
+    suggestion = None
+    if len(losses) > skip_begin + skip_end + 1:
+        window = np.array(losses[skip_begin:-skip_end])
+        suggestion = lrs[skip_begin + int(np.gradient(window).argmin())]
+    return suggestion, lrs, losses

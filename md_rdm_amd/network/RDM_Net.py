@@ -320,7 +320,7 @@ class DepthEstimationNet(BaseModel):
         self._flat = None          # (flat_params, flat_grads, [(name, tensor, offset, numel)])
         self._names = None
         self.direct_grads = False  # True: backward writes straight into the flat gradient buffer (fast path of our harness)
-        self.grad_ready_hook = None  # callable(segment, first_param, last_param) fired after each backward segment (DP overlap)
+        self.grad_ready_hook = None  # callable(stage) fired after each backward stage has been enqueued (DP overlap)
         self.precision = "f32"     # "bf16": eval-mode forward on the bf16 MFMA path (set_precision)
         self._bf16_w = None        # prepared bf16 weights + folded BatchNorm affines (rdm_net_bf16_prepare)
         self._bf16_stale = True
@@ -414,10 +414,10 @@ class DepthEstimationNet(BaseModel):
             gt.append(g.data_ptr() if g is not None else None)
         gtable = (C.c_void_p * len(gt))(*gt)
         st = _lib.stream()
-        for seg in range(4):
-            _lib.check(L.rdm_net_backward(h, _lib.ptr(dlogits), table, gtable, C.c_void_p(self._ws.data_ptr()), ws_bytes, seg, seg, st))
+        for stage in range(L.rdm_net_num_backward_stages()):        # ~25 MB of gradients per stage: the DP exchange starts every few layers
+            _lib.check(L.rdm_net_backward_stage(h, _lib.ptr(dlogits), table, gtable, C.c_void_p(self._ws.data_ptr()), ws_bytes, stage, st))
             if self.grad_ready_hook is not None:
-                self.grad_ready_hook(seg)
+                self.grad_ready_hook(stage)
         out = []
         for k, p, o, n, g in entries:
             if not p.requires_grad or k.startswith("d_1.conv1."):
@@ -495,18 +495,21 @@ class DepthEstimationNet(BaseModel):
         _lib.check(_lib.lib().rdm_net_buffer(h, name.encode(), C.byref(off), C.byref(n)))
         return self._ws[off.value:off.value + 4 * n.value].view(torch.float32)
 
-    def segment_slices(self):
-        """[(start, stop)] element ranges of the flat gradient buffer produced by backward segments 0..3."""
+    def stage_slices(self):
+        """[(start, stop)] element ranges of the flat gradient buffer completed by backward stages 0 .. n-1 (~25 MB each, last
+        registered tensors first: the buckets of the data-parallel gradient exchange)."""
         L = _lib.lib()
         flat, gflat, entries = self._flat
         pos = {k: (o, o + n) for k, p, o, n, g in entries}
         res = []
-        for seg in range(4):
+        for stage in range(L.rdm_net_num_backward_stages()):
             a, b = C.c_int32(), C.c_int32()
-            _lib.check(L.rdm_net_segment_range(seg, C.byref(a), C.byref(b)))
+            _lib.check(L.rdm_net_backward_stage_range(stage, C.byref(a), C.byref(b)))
             ks = [self._names[i] for i in range(a.value, b.value + 1) if self._names[i] in pos]
             res.append((min(pos[k][0] for k in ks), max(pos[k][1] for k in ks)))
         return res
+
+    segment_slices = stage_slices          # former name (4 coarse segments)
 
     # ---- the reference forward (RDM_Net.py:70-135) -----------------------------------------
     def forward(self, x):

@@ -1,12 +1,19 @@
 """Data parallelism for the one exchange step of the path: the gradient all-reduce that Lightning's
 DDP performs implicitly in the reference (train.py:55 ``gpus=N``).
 
-One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm.  The conv-stack
-gradients live in ONE flat buffer; the native backward runs in 4 segments (decoder, e4, e3, e2+stem)
-and after each one the segment's contiguous slice is all-reduced asynchronously - RCCL runs on its
-own HIP stream (fenced by events against the compute stream), so the reduction of segment k overlaps
-the backward of segment k+1.  xGMI is point-to-point: few, large (tens of MB) collectives drive all
-7 links; the 4 slices are 60-150 MB each at fp32.
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm.  The conv-stack gradients live in ONE flat buffer.
+The native backward runs in 13 STAGES of consecutive layers (rdm_net_backward_stage: 12-37 MB of gradients each, the size class
+of DDP's 25 MB buckets, last layers first); after each stage its contiguous slice is all-reduced asynchronously - RCCL runs on
+its own HIP stream, fenced by events against the compute stream - so the reduction of stage k overlaps the backward of stage
+k+1 and only the LAST exchange (12 MB: conv_e1 + the first two dense_e2 layers) is exposed.  xGMI is point-to-point (7 links
+per GPU): tens-of-MB messages keep every link busy; smaller buckets would be latency bound.
+Sums, not means, travel: the optimiser applies 1/world (``grad_scale``), saving a pass over the 362 MB.
+
+BatchNorm buffers: statistics are per-rank in training (local batch, as the reference: no SyncBN).  The reference's DDP
+re-broadcasts module buffers from rank 0 before every forward (torch DDP ``broadcast_buffers=True``), i.e. every rank normalises
+its running_mean / running_var history to rank 0's.  ``GradSync.sync_buffers()`` does exactly that broadcast in one call and
+``attach(..., broadcast_buffers=True)`` (default) runs it at the start of every training forward through a forward pre-hook;
+pass False to keep purely local running statistics.
 The class is independent of the model so that the N>1 logic is testable on CPU with gloo.
 """
 import torch
@@ -14,17 +21,41 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, flat_grad, slices, extra=(), group=None):
+    def __init__(self, flat_grad, slices, extra=(), group=None, buffers=()):
         self.flat, self.slices, self.extra, self.group = flat_grad, list(slices), list(extra), group
+        self.buffers = [b for b in buffers if b.numel()]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles = []
 
-    def on_segment(self, seg):
-        """Call right after backward segment ``seg`` has been enqueued."""
+    def on_segment(self, stage):
+        """Call right after backward stage ``stage`` has been enqueued."""
         if self.world == 1:
             return
-        a, b = self.slices[seg]
+        a, b = self.slices[stage]
         self.handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    on_stage = on_segment
+
+    def sync_buffers(self):
+        """torch DDP's ``broadcast_buffers``: every rank takes rank 0's BatchNorm running statistics / counters."""
+        if self.world == 1 or not self.buffers:
+            return
+        floats = [b for b in self.buffers if b.dtype == torch.float32]
+        if floats:                                                   # one coalesced broadcast instead of ~480 tiny ones
+            buf = torch.cat([b.reshape(-1) for b in floats])
+            dist.broadcast(buf, 0, group=self.group)
+            o = 0
+            for b in floats:
+                b.copy_(buf[o:o + b.numel()].view_as(b))
+                o += b.numel()
+        others = [b for b in self.buffers if b.dtype != torch.float32]
+        if others:
+            buf = torch.cat([b.reshape(-1).to(torch.int64) for b in others])
+            dist.broadcast(buf, 0, group=self.group)
+            o = 0
+            for b in others:
+                b.copy_(buf[o:o + b.numel()].view_as(b).to(b.dtype))
+                o += b.numel()
 
     def finish(self):
         """Wait for all reductions (and reduce the small extra tensors).  Gradients are SUMS;
@@ -45,7 +76,7 @@ class GradSync:
         return 1.0 / self.world
 
 
-def attach(model, group=None):
+def attach(model, group=None, broadcast_buffers=True):
     """Wire a flattened DepthEstimationNet to a GradSync (direct-gradient fast path)."""
     flat, gflat = model._flat[0], model._flat[1]
     if dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -56,7 +87,13 @@ def attach(model, group=None):
         for p in model.weight_layer.parameters():
             if p.numel():
                 dist.broadcast(p.data, 0, group=group)
-    sync = GradSync(gflat, model.segment_slices(), extra=[p for p in model.weight_layer.parameters() if p.requires_grad], group=group)
+    sync = GradSync(gflat, model.stage_slices(), extra=[p for p in model.weight_layer.parameters() if p.requires_grad], group=group,
+                    buffers=list(model.buffers()))
     model.direct_grads = True
-    model.grad_ready_hook = sync.on_segment
+    model.grad_ready_hook = sync.on_stage
+    if broadcast_buffers and sync.world > 1:
+        def _pre(module, args):
+            if module.training:
+                sync.sync_buffers()
+        model._dp_buffer_hook = model.register_forward_pre_hook(_pre)
     return sync

@@ -37,11 +37,17 @@ class ReduceLROnPlateau:
                     g["lr"] = self.opt.lr
                 self.bad = 0
 
+    def state_dict(self):
+        return {"best": self.best, "bad": self.bad, "lr": self.opt.lr}
+
+    def load_state_dict(self, sd):
+        self.best, self.bad = sd["best"], sd["bad"]
+
 
 def main(argv=None):
     parser = ArgumentParser("Trains mono depth estimation models (MI355X-native stack)")
     parser.add_argument("--seed", default=None, type=int)
-    parser.add_argument("--precision", default=32, type=int, help="32 only: the exact-f32 MFMA path (the reference's AMP 16 is a later round)")
+    parser.add_argument("--precision", default=32, type=int, help="32: exact-f32 MFMA training and validation; 16: f32 training with the VALIDATION forward on the bf16 MFMA path (the reference's AMP O2, train.py:57-58, has no bf16 backward counterpart here)")
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--dev", action="store_true", help="one train + one val step (Lightning fast_dev_run)")
     parser.add_argument("--overfit", action="store_true", help="reuse one batch")
@@ -61,16 +67,26 @@ def main(argv=None):
     parser.add_argument("--resume", type=str, default=None, help="Lightning .ckpt or state_dict to start from")
     parser.add_argument("--relative_decoders", type=int, nargs="*", default=[], help="subset of 6 7 8 9: the relative decoders the reference keeps commented out (RDM_Net.py:57-60)")
     args = parser.parse_args(argv)
-    if args.precision != 32:
-        raise SystemExit("only --precision 32 is built")
+    if args.precision not in (16, 32):
+        raise SystemExit("--precision must be 16 or 32")
     if not args.synthetic and not args.nyu_path:
         raise SystemExit("give --nyu_path DIR (raw .h5 / .npz samples) or --synthetic")
+    if args.detect_anomaly:                                  # train.py:28-30
+        print("Enabling anomaly detection")
+        torch.autograd.set_detect_anomaly(True)
+    if args.min_epochs > args.max_epochs:
+        raise SystemExit(f"--min_epochs {args.min_epochs} > --max_epochs {args.max_epochs}: min_epochs only holds back an early stop (Lightning), "
+                         "and like the reference this trainer has none - it always runs max_epochs")
     if args.seed is None:
         args.seed = random.randrange(4294967295)
     torch.manual_seed(args.seed)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # the reference's `gpus=N` makes Lightning spawn N DDP ranks itself (train.py:55); here one process per GPU is started by the launcher
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: start one rank per GPU, e.g.\n  python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 -m md_rdm_amd.train --gpus {args.gpus} ...")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -82,14 +98,25 @@ def main(argv=None):
     from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
     model = DepthEstimationNet(relative_decoders=tuple(args.relative_decoders)).to(dev)
+    resumed = None
     if args.resume:
         from .checkpoint import from_lightning
-        from_lightning(model, args.resume)
+        _, resumed = from_lightning(model, args.resume)
     model.flatten_parameters()
     sync = parallel.attach(model)
     best_delta1, best_path = None, None
     opt = harness.FusedAdamW(model, lr=args.learning_rate)
     sched = ReduceLROnPlateau(opt, "max", patience=2)
+    start_epoch = 0
+    if resumed is not None:
+        from .checkpoint import restore_training_state
+        if restore_training_state(resumed, opt, sched):          # one of OUR checkpoints: moments, step, lr, plateau state, epoch
+            start_epoch = int(resumed.get("epoch", -1)) + 1
+            best_delta1 = resumed.get("best_val_delta1")
+            if rank == 0:
+                print(f"resumed optimiser state at step {opt.step_count}, lr {opt.lr:g}, continuing with epoch {start_epoch}", flush=True)
+        elif rank == 0:
+            print("resumed WEIGHTS only (the checkpoint carries no fused-optimiser state, e.g. a reference Lightning .ckpt)", flush=True)
     logger = MetricLogger(args.metrics if "delta1" in args.metrics else ["delta1"] + list(args.metrics))
     H, W = args.size
     steps = 1 if args.dev else args.max_steps
@@ -97,8 +124,9 @@ def main(argv=None):
     if args.nyu_path:
         from .dataloaders import NYUDataset, PrefetchLoader
         train_loader = PrefetchLoader(NYUDataset(args.nyu_path, split="train", output_size=(H, W)), args.batch_size, seed=args.seed, device=dev,
-                                      rank=rank, world=world)
-        val_loader = PrefetchLoader(NYUDataset(args.nyu_path, split="val", output_size=(H, W)), 1, device=dev, drop_last=False, rank=rank, world=world)
+                                      rank=rank, world=world, workers=args.worker)
+        val_loader = PrefetchLoader(NYUDataset(args.nyu_path, split="val", output_size=(H, W)), 1, device=dev, drop_last=False, rank=rank, world=world,
+                                    workers=args.worker)
         steps = 1 if args.dev else len(train_loader)
 
     def train_batches(epoch):
@@ -115,8 +143,19 @@ def main(argv=None):
             x, y = filler.synthetic_batch(args.batch_size, H, W, seed=seed)
             yield torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
 
-    for epoch in range(args.max_epochs):
+    if args.find_learning_rate:                                  # train.py:74-80: the finder runs INSTEAD of fit
         model.train()
+        suggestion, lrs, losses = harness.find_learning_rate(model, opt, train_batches(0), sync=sync)
+        if rank == 0:
+            print("Old learning rate: ", args.learning_rate)
+            print("Suggested learning rate: ", suggestion, f"({len(lrs)} steps swept, lr {lrs[0]:.1e} .. {lrs[-1]:.1e})")
+        if world > 1:
+            dist.destroy_process_group()
+        return suggestion
+
+    for epoch in range(start_epoch, args.max_epochs):
+        model.train()
+        model.set_precision("f32")
         t0 = time.time()
         for it, (x, y) in enumerate(train_batches(epoch)):
             opt.zero_grad()
@@ -128,6 +167,7 @@ def main(argv=None):
                       f"Fine_Detail {parts['fine_detail_loss'].item():.4f}", flush=True)
         torch.cuda.synchronize()
         model.eval()
+        model.set_precision("bf16" if args.precision == 16 else "f32")
         with torch.no_grad():
             logger.reset()
             if val_loader is not None:
@@ -146,7 +186,7 @@ def main(argv=None):
             from .checkpoint import to_lightning
             os.makedirs(args.checkpoint_dir, exist_ok=True)
             path = os.path.join(args.checkpoint_dir, f"epoch={epoch}-val_delta1={d1:.4f}.ckpt")
-            torch.save(to_lightning(model, {"epoch": epoch, "global_step": (epoch + 1) * steps}), path)
+            torch.save(to_lightning(model, {"epoch": epoch, "global_step": (epoch + 1) * steps, "best_val_delta1": d1}, optimizer=opt, scheduler=sched), path)
             if best_path and best_path != path and os.path.exists(best_path):
                 os.remove(best_path)
             best_delta1, best_path = d1, path

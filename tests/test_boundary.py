@@ -127,8 +127,88 @@ def test_lightning_checkpoint_wire_format(tmp_path):
     path = tmp_path / "last.ckpt"
     torch.save(ck, path)
     b = DepthEstimationNet()
-    res = checkpoint.from_lightning(b, str(path))
+    res, _ = checkpoint.from_lightning(b, str(path))
     assert not res.missing_keys and not res.unexpected_keys
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
     checkpoint.from_lightning(b, a.state_dict())        # a bare state_dict is accepted too
+
+
+def test_genuine_lightning_checkpoint_with_foreign_classes_loads_without_lightning(tmp_path):
+    """A real Lightning 1.1.x .ckpt (train.py:41-47) pickles non-tensor classes: ``hyper_parameters`` is an AttributeDict
+    (save_hyperparameters) and ``callbacks`` is keyed by the ModelCheckpoint CLASS.  torch >= 2.6's weights_only=True refuses them
+    and pytorch_lightning is not installed here - the loader must still extract the 968 tensors, without importing anything."""
+    import sys
+    import types
+    import torch
+    from md_rdm_amd import checkpoint, filler
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    a = DepthEstimationNet()
+    filler.fill_state_dict(a.state_dict())
+    names = ["pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing", "pytorch_lightning.callbacks",
+             "pytorch_lightning.callbacks.model_checkpoint"]
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class AttributeDict(dict):
+        pass
+
+    class ModelCheckpoint:
+        pass
+    AttributeDict.__module__, AttributeDict.__qualname__ = "pytorch_lightning.utilities.parsing", "AttributeDict"
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = "pytorch_lightning.callbacks.model_checkpoint", "ModelCheckpoint"
+    mods["pytorch_lightning.utilities.parsing"].AttributeDict = AttributeDict
+    mods["pytorch_lightning.callbacks.model_checkpoint"].ModelCheckpoint = ModelCheckpoint
+    sys.modules.update(mods)
+    try:
+        ck = checkpoint.to_lightning(a, {"epoch": 3, "global_step": 1234})
+        ck["hyper_parameters"] = AttributeDict(batch_size=4, learning_rate=1e-4, metrics=["delta1"])
+        ck["callbacks"] = {ModelCheckpoint: {"best_model_score": torch.tensor(0.5), "best_model_path": "x.ckpt"}}
+        ck["optimizer_states"] = [{"state": {0: {"step": 5, "exp_avg": torch.zeros(3), "exp_avg_sq": torch.zeros(3)}}, "param_groups": [{"lr": 1e-4, "params": [0]}]}]
+        ck["lr_schedulers"] = [{"best": 0.5, "num_bad_epochs": 1}]
+        path = tmp_path / "epoch=3-val_delta1=0.5.ckpt"
+        torch.save(ck, path)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)           # what the old loader did
+    b = DepthEstimationNet()
+    res, loaded = checkpoint.from_lightning(b, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    assert loaded["epoch"] == 3 and loaded["global_step"] == 1234
+    assert "pytorch_lightning" not in sys.modules                          # nothing foreign was imported or executed
+
+    class FakeOpt:
+        def load_state_dict(self, sd):
+            raise AssertionError("a reference (torch.optim) optimizer state must not be pushed into the fused optimiser")
+    assert checkpoint.restore_training_state(loaded, FakeOpt()) is False    # weights-only resume for reference checkpoints
+
+
+def test_reduce_lr_on_plateau_matches_torch():
+    """module.py:42-46: ReduceLROnPlateau(optimizer, 'max', patience=2) on val_delta1 - same lr trajectory as torch's scheduler."""
+    import torch
+    from md_rdm_amd.train import ReduceLROnPlateau
+
+    class Opt:
+        lr = 1e-4
+
+        class small:
+            param_groups = [{"lr": 1e-4}]
+    o = Opt()
+    mine = ReduceLROnPlateau(o, "max", patience=2)
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.AdamW([p], lr=1e-4)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, "max", patience=2)
+    seq = [0.30, 0.31, 0.31, 0.309, 0.31, 0.305, 0.4, 0.4, 0.39, 0.4, 0.40001, 0.2, 0.2, 0.2, 0.2, 0.2]
+    for v in seq:
+        mine.step(v)
+        ref.step(v)
+        assert abs(o.lr - topt.param_groups[0]["lr"]) <= 1e-18 + 1e-12 * o.lr, (v, o.lr, topt.param_groups[0]["lr"])
+        assert o.small.param_groups[0]["lr"] == o.lr
+    assert o.lr < 1e-5                                                      # it did decay (twice) on this sequence
+    st = mine.state_dict()
+    again = ReduceLROnPlateau(Opt(), "max", patience=2)
+    again.load_state_dict(st)
+    assert again.best == mine.best and again.bad == mine.bad

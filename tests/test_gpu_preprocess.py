@@ -130,12 +130,70 @@ def test_train_script_on_a_raw_dataset(tmp_path, capsys):
     assert "nan" not in out.lower()
     saved = list(ck.glob("*.ckpt"))
     assert len(saved) == 1                                           # save_top_k = 1
-    state = torch.load(saved[0], map_location="cpu")["state_dict"]
+    ckpt = torch.load(saved[0], map_location="cpu")
+    state = ckpt["state_dict"]
     assert len(state) == 968 and all(k.startswith("model.") for k in state)
-    train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1", "--resume", str(saved[0])])
+    # the checkpoint carries the training state too (Lightning's top-level keys): fused-optimiser moments / step / lr, plateau scheduler
+    opt_state = ckpt["optimizer_states"][0]
+    assert opt_state["step"] == 2 * (ckpt["epoch"] + 1) and opt_state["exp_avg"].numel() > 90_000_000 and float(opt_state["exp_avg"].abs().max()) > 0
+    assert "best" in ckpt["lr_schedulers"][0]
+    train.main(["--synthetic", "--batch_size", "2", "--seed", "1", "--max_steps", "1", "--max_epochs", str(ckpt["epoch"] + 2), "--resume", str(saved[0])])
+    out = capsys.readouterr().out
+    assert f"resumed optimiser state at step {opt_state['step']}" in out and f"epoch {ckpt['epoch'] + 1} step 0 loss" in out
+    assert f"epoch {ckpt['epoch']} step" not in out                   # continues after the saved epoch, does not repeat it
 
 
 def test_train_script_synthetic_dev_run(capsys):
     from md_rdm_amd import train
     train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1"])
     assert "epoch 0 step 0 loss" in capsys.readouterr().out
+
+
+def test_train_script_flags_work_or_raise(capsys):
+    """train.py:9-30,55,74-80: no flag is silently ignored."""
+    from md_rdm_amd import train
+    with pytest.raises(SystemExit) as e:                               # gpus=N needs N launched ranks
+        train.main(["--synthetic", "--dev", "--gpus", "8"])
+    assert "WORLD_SIZE" in str(e.value) and "torch.distributed.run" in str(e.value)
+    with pytest.raises(SystemExit):
+        train.main(["--synthetic", "--dev", "--min_epochs", "5", "--max_epochs", "2"])
+    with pytest.raises(SystemExit):
+        train.main(["--synthetic", "--dev", "--precision", "8"])
+    # --detect_anomaly switches autograd anomaly mode on (train.py:28-30) and the native autograd node runs under it
+    try:
+        train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1", "--detect_anomaly"])
+        assert torch.is_anomaly_enabled()
+    finally:
+        torch.autograd.set_detect_anomaly(False)
+    assert "Enabling anomaly detection" in capsys.readouterr().out
+    # --precision 16: training stays f32, the validation forward runs on the bf16 MFMA path
+    train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1", "--precision", "16"])
+    out = capsys.readouterr().out
+    assert "epoch 0 step 0 loss" in out and "val_delta1" in out and "nan" not in out.lower()
+
+
+def test_find_learning_rate_sweeps_and_restores(capsys):
+    """train.py:74-80 / Lightning lr_find: exponential sweep 1e-8 -> 1, smoothed loss, early stop at 4x the best, suggestion at the
+    steepest descent; the model and optimiser come back untouched."""
+    from md_rdm_amd import filler, harness
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    dev = torch.device("cuda:0")
+    m = DepthEstimationNet()
+    filler.fill_state_dict(m.state_dict())
+    m = m.to(dev).train()
+    m.flatten_parameters()
+    m.direct_grads = True
+    opt = harness.FusedAdamW(m, lr=1e-4)
+    x, y = filler.synthetic_batch(2, 226, 226, seed=4)
+    batch = (torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sug, lrs, losses = harness.find_learning_rate(m, opt, [batch], num_training=40)
+    assert 12 < len(lrs) <= 40 and abs(lrs[0] - 1e-8) < 1e-20 and all(b > a for a, b in zip(lrs, lrs[1:]))
+    assert sug is not None and lrs[10] <= sug <= lrs[-1] and all(np.isfinite(losses[:-1]))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                           # weights, BatchNorm buffers and counters restored
+    assert opt.step_count == 0 and opt.lr == 1e-4 and float(opt.m.abs().max()) == 0
+    from md_rdm_amd import train
+    assert train.main(["--synthetic", "--batch_size", "2", "--seed", "1", "--find_learning_rate"]) is not None
+    out = capsys.readouterr().out
+    assert "Old learning rate:" in out and "Suggested learning rate:" in out and "epoch 0 step" not in out   # the finder runs INSTEAD of fit

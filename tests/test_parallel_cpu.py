@@ -26,6 +26,11 @@ def _worker(rank, world, port, q):
     scale = sync.finish()
     want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = torch.equal(flat, want) and abs(scale - 1.0 / world) < 1e-12 and abs(w.grad.item() - (1 + world) / 2) < 1e-6
+    # torch DDP's broadcast_buffers: BatchNorm running statistics and counters follow rank 0
+    rm, nbt = torch.full((7,), float(rank + 3)), torch.tensor(rank + 5, dtype=torch.int64)
+    sb = GradSync(flat, slices, buffers=[rm, nbt, torch.zeros(0)])
+    sb.sync_buffers()
+    ok = ok and torch.equal(rm, torch.full((7,), 3.0)) and int(nbt) == 5 and nbt.dtype == torch.int64
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -50,3 +55,25 @@ def test_gradsync_single_process_is_noop():
     for seg in range(4):
         s.on_segment(seg)
     assert s.finish() == 1.0 and torch.equal(flat, torch.ones(10))
+
+
+def test_backward_stages_partition_the_stack_into_ddp_sized_buckets():
+    """rdm_net_backward_stage: the stages tile the conv stack's tensors exactly once, last registered tensor first, in buckets of
+    the size class of DDP's 25 MB default (train.py:55) with a small LAST exchange."""
+    import ctypes as C
+    from md_rdm_amd import _lib
+    L = _lib.lib()
+    n = L.rdm_net_num_backward_stages()
+    assert 10 <= n <= 20
+    nxt, sizes = None, []
+    for s in range(n):
+        a, b = C.c_int32(), C.c_int32()
+        assert L.rdm_net_backward_stage_range(s, C.byref(a), C.byref(b)) == 0
+        assert a.value <= b.value and (nxt is None or b.value == nxt - 1)         # contiguous, walking backwards
+        nxt = a.value
+        sizes.append(4 * sum(L.rdm_net_tensor_numel(i) for i in range(a.value, b.value + 1) if L.rdm_net_tensor_is_param(i)))
+    assert nxt == 0                                                               # ... down to encoder.conv_e1.weight
+    assert L.rdm_net_tensor_name(L.rdm_net_num_tensors() - 9).decode() == "d_1.conv2.bias"   # stage 0 ends at the last stack tensor (8 weight_layer entries follow)
+    assert sum(sizes) == 4 * (90529721 - 4)                                       # every stack parameter exactly once (the 4 Weights scalars are exchanged apart)
+    assert all(10e6 < z < 40e6 for z in sizes) and sizes[-1] < 15e6               # the exposed last exchange is the smallest
+    assert L.rdm_net_backward_stage_range(n, C.byref(a), C.byref(b)) != 0
