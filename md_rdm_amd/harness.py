@@ -147,13 +147,16 @@ def find_learning_rate(model, opt, batches, min_lr=1e-8, max_lr=1.0, num_trainin
     saved = (flat.detach().clone(), {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("weight_layer.") or "running_" in k or "num_batches" in k},
              opt.state_dict())
     lrs, losses, avg, best = [], [], 0.0, None
-    it = iter(batches)
+    seen, it = [], iter(batches)
     for i in range(num_training):
         try:
             x, y = next(it)
+            if len(seen) < 64:
+                seen.append((x, y))                                  # a one-shot generator is cycled from what it yielded
         except StopIteration:
-            it = iter(batches)
-            x, y = next(it)
+            if not seen:
+                raise ValueError("find_learning_rate: no batches")
+            x, y = seen[i % len(seen)]
         lr = min_lr * (max_lr / min_lr) ** (i / max(num_training - 1, 1))
         opt.lr = lr
         for g in opt.small.param_groups:

@@ -38,13 +38,14 @@ def test_two_rank_train_step_matches_single_process_with_averaged_gradients(tmp_
             p.kill()
             outs.append(p.communicate()[0])
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    print("\n".join(o[-1500:] for o in outs))                        # phase timings of the ranks (pytest -s)
+    r0, r1 = ({k: v for k, v in np.load(tmp_path / f"rank{r}.npz").items()} for r in range(2))     # materialise once: NpzFile re-reads per access
     assert int(r0["n_slices"]) == 13 and float(r0["scale"]) == 0.5
     # ---- replicas stay identical ----
     np.testing.assert_array_equal(r0["init"], r1["init"])          # attach() broadcast rank 0's parameters over rank 1's perturbed ones
     np.testing.assert_array_equal(r0["gsum"], r1["gsum"])
     np.testing.assert_array_equal(r0["post"], r1["post"])
-    for k in r0.files:
+    for k in r0:
         if k.startswith("wlp_") or k.startswith("wl_"):
             np.testing.assert_array_equal(r0[k], r1[k])
     assert float(r0["loss"]) != float(r1["loss"])                  # ... although they saw different shards
@@ -63,7 +64,7 @@ def test_two_rank_train_step_matches_single_process_with_averaged_gradients(tmp_
     shard_g, wl_g, rm_after = [], [], []
     for r in range(2):
         m.load_state_dict(sd0)                                     # both shards start from the same weights and BatchNorm buffers
-        x, y = filler.synthetic_batch(2, 228, 228, seed=100 + r)
+        x, y = filler.synthetic_batch(2, 228, 228, seed=(7, 14)[r])   # seeds with finite losses (no zero ordinal count)
         for p in m.weight_layer.parameters():
             p.grad = None
         loss, _ = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))

@@ -194,6 +194,6 @@ def test_find_learning_rate_sweeps_and_restores(capsys):
         assert torch.equal(v, before[k]), k                           # weights, BatchNorm buffers and counters restored
     assert opt.step_count == 0 and opt.lr == 1e-4 and float(opt.m.abs().max()) == 0
     from md_rdm_amd import train
-    assert train.main(["--synthetic", "--batch_size", "2", "--seed", "1", "--find_learning_rate"]) is not None
+    assert train.main(["--synthetic", "--overfit", "--batch_size", "2", "--seed", "1", "--find_learning_rate"]) is not None
     out = capsys.readouterr().out
     assert "Old learning rate:" in out and "Suggested learning rate:" in out and "epoch 0 step" not in out   # the finder runs INSTEAD of fit
