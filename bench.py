@@ -95,6 +95,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    launches0 = L.rdm_launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -102,6 +103,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    lib_launches_per_step = (L.rdm_launch_count() - launches0) / args.steps
     if not args.no_roofline:
         # roofline leg: the SAME K steps again, immediately after the timed region, with a HIP event pair
         # recorded around every conv launch (the events cost ~3.5 us each between dependent kernels,
@@ -143,7 +145,8 @@ def main():
         roof = {"bound": "mfma", "kernel": "conv_fwd_kernel/conv_wgrad_kernel (fp32 MFMA 16x16x4 implicit GEMM)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "per_kernel": per_kernel,
-                "launches_per_step": n.value // max(args.steps, 1), "kernel_ms_per_step": round(ms.value / args.steps, 3),
+                "launches_per_step": n.value // max(args.steps, 1), "library_launches_per_step_all_kernels": round(lib_launches_per_step, 1),
+                "kernel_ms_per_step": round(ms.value / args.steps, 3),
                 "kernel_ms_sum_per_step": round(ms_sum.value / args.steps, 3),
                 "timing": "HIP events on the launch streams over K further steps run right after the timed region; kernel_ms = union of the conv kernels' intervals (wgrad kernels overlap the dgrad chain on a side stream)",
                 "executed_tflop_per_step": round(fl.value / args.steps / 1e12, 4), "algorithmic_tflop_per_step": round(algo / args.steps / 1e12, 4)}

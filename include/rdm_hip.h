@@ -58,6 +58,9 @@ double rdm_profile_kind_bytes(int32_t kind);
  * 13 128x96 wgrad tiles only, 14 default-priority side stream, 16/20 256x48 tiles on 1x1 convs, 21 256-pixel halo tiles only,
  * 23 full-size wgrad tiles at small M, 26 hand-pipelined (251-VGPR) row wgrad.  Results never depend on it beyond float rounding. */
 void rdm_debug_variant(int32_t v);
+/* number of kernel-launching calls the library has made in this process (monotonic; bench.py reports the per-step difference;
+ * a K-split launcher that also enqueues its zero-fill or reduction counts once per enqueued kernel family) */
+int64_t rdm_launch_count(void);
 
 /* Attainable-peak microbenchmarks: float4 stream copy (HBM) and a register-only
  * v_mfma_f32_16x16x4_f32 loop (blocks x 4 waves x iters x 12 MFMAs of 2048 FLOP). */
@@ -183,6 +186,16 @@ int rdm_net_create(int32_t batch, int32_t height, int32_t width, rdm_net** out);
 void rdm_net_destroy(rdm_net* net);
 size_t rdm_net_workspace_bytes(const rdm_net* net);
 int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
+/* Plan options (all default 0 = `tensors` / `grads` exactly as the reference's state_dict lays them out, the plan zeroes what it
+ * accumulates into):
+ *   RDM_NET_OPT_PACKED_3X3       the 78 dense-layer 3x3 weights `...denselayerN.conv2.weight` - and their gradients - are handed over
+ *                                PACKED [tap][out][in] instead of PyTorch's [out][in][kh][kw] (md_rdm_amd keeps them packed inside its
+ *                                flat parameter buffer and exposes OIHW-shaped strided views): removes 78 pack launches per forward
+ *                                and 78 unpack launches + 78 scratch fills per backward.
+ *   RDM_NET_OPT_GRADS_PREZEROED  the caller guarantees that every gradient tensor is all zero when backward stage 0 starts (one fill
+ *                                of a flat gradient buffer instead of ~160 per-tensor fills inside the plan). */
+typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2 } rdm_net_option;
+int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */
 int rdm_net_forward(rdm_net* net, const float* x_nchw, void* const* tensors, void* workspace, size_t workspace_bytes,

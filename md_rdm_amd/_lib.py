@@ -24,6 +24,7 @@ _SIGNATURES = {
     "rdm_version": (C.c_int, []),
     "rdm_profile_enable": (None, [i32]),
     "rdm_debug_variant": (None, [i32]),
+    "rdm_launch_count": (i64, []),
     "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind": (C.c_int, [i32, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind_bytes": (f64, [i32]),
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "rdm_net_create": (C.c_int, [i32, i32, i32, C.POINTER(vp)]),
     "rdm_net_destroy": (None, [vp]),
     "rdm_net_workspace_bytes": (sz, [vp]),
+    "rdm_net_set_option": (C.c_int, [vp, i32, i32]),
     "rdm_net_output_hw": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "rdm_net_forward": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, i32, vp]),
     "rdm_net_bf16_weight_bytes": (sz, [vp]),

@@ -9,6 +9,7 @@
 
 namespace rdm {
 extern int g_variant;
+long long g_launches = 0;
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -37,6 +38,7 @@ const char* rdm_last_error_string(void) { return g_err; }
 int rdm_version(void) { return 100; }
 
 void rdm_debug_variant(int32_t v) { rdm::g_variant = v; }
+int64_t rdm_launch_count(void) { return rdm::g_launches; }
 void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches) {
   int n = 0;

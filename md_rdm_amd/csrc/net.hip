@@ -174,6 +174,8 @@ struct NetImpl {
   }
   size_t total;
   int training_saved = 1;
+  int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
+  int opt_prezeroed = 0;       // RDM_NET_OPT_GRADS_PREZEROED: every gradient tensor is zero when backward stage 0 starts
   // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
   struct Bf16Layer { size_t w1, w3, bn1, bn2; };
   std::vector<Bf16Layer> bfl[4];
@@ -397,7 +399,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
                                  static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
       return rc;
-    float* w2p = at<float>(ws, W.w2p);            // packed on the side stream at the start of forward
+    const float* w2p = n.opt_packed3x3 ? F(T, L.conv2) : at<float>(ws, W.w2p);     // else packed on the side stream at the start of forward
     if (b == 0 && i == 0) RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
     FwdArgs c{};
     c.g = geom3x3(n.B, g.H, g.W, 1);
@@ -465,22 +467,23 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const*
     float* Y = at<float>(ws, W.Y);
     float* bn1 = at<float>(ws, W.bn1);
     float* bn2 = at<float>(ws, W.bn2);
-    float* w2p = at<float>(ws, W.w2p);
+    const float* w2p = n.opt_packed3x3 ? F(T, L.conv2) : at<float>(ws, W.w2p);
     const float* go = G + cin;
     // the layer's output gradient `go` is final here (all later layers have accumulated into it)
     RDM_HIP_OK(hipEventRecord(n.ev_go, s));
     // ---- side stream: conv2 (3x3) wgrad ----
     if (Gr[L.conv2]) {
-      float* dW3 = at<float>(ws, W.dw3);
+      // packed gradients go straight to the caller's tensor; otherwise into a scratch that is unpacked to OIHW afterwards
+      float* dW3 = n.opt_packed3x3 ? F(Gr, L.conv2) : at<float>(ws, W.dw3);
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_go, 0));
-      if ((rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
+      if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
       WgradArgs w{};
       w.g = geom3x3(n.B, g.H, g.W, 1);
       w.G = go; w.ldg = g.ctot; w.N = GROWTH;
       w.Xs = Y; w.ldx = cb; w.C = cb; w.x_scale = bn2; w.x_shift = bn2 + cb;
       w.dW = dW3; w.wtap = (long)GROWTH * cb; w.ldw = cb;
       if ((rc = launch_conv_wgrad(w, side))) return rc;
-      if ((rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, side))) return rc;
+      if (!n.opt_packed3x3 && (rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, side))) return rc;
     }
     // ---- main: conv2 dgrad -> dZ[par], gated by relu2, with the norm2 backward reductions ----
     if (n.dz_busy[par]) { RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_dz[par], 0)); n.dz_busy[par] = false; }   // side wgrad still reading this buffer?
@@ -502,7 +505,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const*
     if (Gr[L.conv1]) {
       RDM_HIP_OK(hipEventRecord(n.ev_dy, s));
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_dy, 0));
-      if ((rc = zero_f32(F(Gr, L.conv1), (size_t)cb * cin, side))) return rc;
+      if (!n.opt_prezeroed && (rc = zero_f32(F(Gr, L.conv1), (size_t)cb * cin, side))) return rc;
       WgradArgs w{};
       w.g = geom1x1(n.B, g.H, g.W);
       w.G = dZ; w.ldg = cb; w.N = cb;
@@ -551,7 +554,7 @@ int backward_transition(NetImpl& n, int t, void* ws, void* const* T, void* const
   const int wi = reg().trans_conv[t];
   int rc;
   if (Gr[wi]) {
-    if ((rc = zero_f32(F(Gr, wi), (size_t)Co * C, s))) return rc;
+    if (!n.opt_prezeroed && (rc = zero_f32(F(Gr, wi), (size_t)Co * C, s))) return rc;
     WgradArgs w{};
     w.g = geom1x1(n.B, gn.H, gn.W);
     w.G = Gn; w.ldg = gn.ctot; w.N = Co;
@@ -604,6 +607,15 @@ int rdm_net_create(int32_t batch, int32_t height, int32_t width, rdm_net** out) 
 
 void rdm_net_destroy(rdm_net* net) { delete reinterpret_cast<NetImpl*>(net); }
 size_t rdm_net_workspace_bytes(const rdm_net* net) { return net ? reinterpret_cast<const NetImpl*>(net)->total : 0; }
+
+int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
+  RDM_CHECK_ARG(net != nullptr, "net is NULL");
+  NetImpl* n = reinterpret_cast<NetImpl*>(net);
+  if (option == RDM_NET_OPT_PACKED_3X3) n->opt_packed3x3 = value != 0;
+  else if (option == RDM_NET_OPT_GRADS_PREZEROED) n->opt_prezeroed = value != 0;
+  else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
+  return RDM_OK;
+}
 
 int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w) {
   RDM_CHECK_ARG(net && h && w, "NULL argument");
@@ -665,12 +677,14 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
   if (training) RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.stats_begin), 0, n.stats_end - n.stats_begin, s));
   // the 78 3x3 weights are re-packed to [tap][out][in] once per forward, off the critical path: on the
   // library's side stream, fenced against the caller's stream on both ends
+  // (with RDM_NET_OPT_PACKED_3X3 the caller keeps them packed and these 78 launches do not exist)
   if ((rc = n.ensure_side())) return rc;
   RDM_HIP_OK(hipEventRecord(n.ev_go, s));
   RDM_HIP_OK(hipStreamWaitEvent(n.side, n.ev_go, 0));
-  for (int b = 0; b < 4; ++b)
-    for (int i = 0; i < kBlocks[b].layers; ++i)
-      if ((rc = launch_pack_w(F(T, reg().layers[b][i].conv2), at<float>(ws, n.lws[b][i].w2p), GROWTH, n.bg[b].cb, 9, GROWTH, n.side))) return rc;
+  if (!n.opt_packed3x3)
+    for (int b = 0; b < 4; ++b)
+      for (int i = 0; i < kBlocks[b].layers; ++i)
+        if ((rc = launch_pack_w(F(T, reg().layers[b][i].conv2), at<float>(ws, n.lws[b][i].w2p), GROWTH, n.bg[b].cb, 9, GROWTH, n.side))) return rc;
   RDM_HIP_OK(hipEventRecord(n.ev_side, n.side));
   // stem: 7x7/s2 conv as im2col + GEMM (K = 147 padded to 160), bias, then 3x3/s2 max-pool
   if ((rc = launch_im2col_stem(x, at<float>(ws, n.patches), n.B, n.H0, n.W0, s))) return rc;
@@ -735,7 +749,8 @@ int rdm_net_bf16_prepare(rdm_net* net, void* const* T, void* wbuf, size_t wbuf_b
       const NetImpl::Bf16Layer& W = n.bfl[b][i];
       const int cin = kBlocks[b].cin + i * GROWTH, cb = n.bg[b].cb;
       if ((rc = launch_f32_to_bf16_rows(F(T, L.conv1), cin, at<char>(wbuf, W.w1), cin, cb, cin, cin, s))) return rc;
-      if ((rc = launch_pack_w_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), GROWTH, cb, 9, s))) return rc;
+      if (n.opt_packed3x3) { if ((rc = launch_f32_to_bf16_rows(F(T, L.conv2), cb, at<char>(wbuf, W.w3), cb, 9L * GROWTH, cb, cb, s))) return rc; }
+      else if ((rc = launch_pack_w_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), GROWTH, cb, 9, s))) return rc;
       if ((rc = affine(L.bn1, W.bn1, cin))) return rc;
       if ((rc = affine(L.bn2, W.bn2, cb))) return rc;
     }
@@ -827,7 +842,7 @@ static int backward_head(NetImpl& n, const float* dlogits, void* ws, void* const
     if ((rc = launch_f64_to_f32(t64, F(Gr, bi), 180, s))) return rc;
   }
   if (Gr[wi]) {
-    if ((rc = zero_f32(F(Gr, wi), (size_t)180 * 2208, s))) return rc;
+    if (!n.opt_prezeroed && (rc = zero_f32(F(Gr, wi), (size_t)180 * 2208, s))) return rc;
     WgradArgs w{};
     w.g = geom1x1(n.B, g.H, g.W);
     w.G = dL; w.ldg = 192; w.N = 180;

@@ -27,9 +27,12 @@ void set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
-// every launcher ends with this: catches bad launch configs without synchronising
+// every launcher ends with this: catches bad launch configs without synchronising (and counts the launcher calls for
+// rdm_launch_count(): bench.py reports launches per step)
+extern long long g_launches;
 #define RDM_LAUNCH_OK()                                                               \
   do {                                                                                \
+    ++::rdm::g_launches;                                                              \
     hipError_t e_ = hipGetLastError();                                                \
     if (e_ != hipSuccess) {                                                           \
       ::rdm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \

@@ -350,7 +350,11 @@ class DepthEstimationNet(BaseModel):
     def flatten_parameters(self):
         """Re-home every conv-stack parameter into ONE contiguous buffer (and a twin gradient
         buffer) so the optimiser and the gradient all-reduce are single flat operations.
-        Parameter objects keep their identity; only ``.data`` is re-pointed."""
+        Parameter objects keep their identity; only ``.data`` is re-pointed.
+        The 78 dense-layer 3x3 weights live there PACKED [tap][out][in] - the layout the MFMA kernels read (forward rows, dgrad
+        columns) and the weight-gradient kernel writes - and ``.data`` / ``.grad`` are OIHW-shaped strided VIEWS of it, so
+        state_dict / checkpoints / tests see PyTorch's logical tensor while no pack / unpack pass ever runs (AdamW is elementwise:
+        parameter, gradient and moments share the layout)."""
         ps = self.stack_parameters()
         dev = ps[0][1].device
         offs, off = [], 0
@@ -359,12 +363,19 @@ class DepthEstimationNet(BaseModel):
             off += (p.numel() + 63) // 64 * 64          # 256-byte alignment of every tensor
         flat = torch.zeros(off, dtype=torch.float32, device=dev)
         gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+
+        def view_of(buf, k, p, o, n):
+            if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and ".denselayer" in k:
+                O, I = p.shape[0], p.shape[1]
+                return buf[o:o + n].view(9, O, I).permute(1, 2, 0).unflatten(2, (3, 3))      # (O, I, 3, 3), strides (I, 1, 3*O*I, O*I)
+            return buf[o:o + n].view(p.shape)
         entries = []
         for (k, p), o in zip(ps, offs):
             n = p.numel()
-            flat[o:o + n].copy_(p.data.reshape(-1))
-            p.data = flat[o:o + n].view(p.shape)
-            entries.append((k, p, o, n, gflat[o:o + n].view(p.shape)))
+            v = view_of(flat, k, p, o, n)
+            v.copy_(p.data)
+            p.data = v
+            entries.append((k, p, o, n, view_of(gflat, k, p, o, n)))
         self._flat = (flat, gflat, entries)
         return flat, gflat
 
@@ -378,6 +389,8 @@ class DepthEstimationNet(BaseModel):
             L = _lib.lib()
             h = C.c_void_p()
             _lib.check(L.rdm_net_create(B, H, W, C.byref(h)))
+            _lib.check(L.rdm_net_set_option(h, 1, 1))         # RDM_NET_OPT_PACKED_3X3: flatten_parameters keeps the 3x3 weights packed
+            _lib.check(L.rdm_net_set_option(h, 2, 1))         # RDM_NET_OPT_GRADS_PREZEROED: _native_backward fills the flat gradient buffer once
             oh, ow = C.c_int32(), C.c_int32()
             _lib.check(L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)))
             self._plans[key] = (h, int(L.rdm_net_workspace_bytes(h)), oh.value, ow.value)
@@ -414,6 +427,7 @@ class DepthEstimationNet(BaseModel):
             gt.append(g.data_ptr() if g is not None else None)
         gtable = (C.c_void_p * len(gt))(*gt)
         st = _lib.stream()
+        gflat.zero_()                                                # ONE fill instead of ~160 per-tensor fills inside the plan
         for stage in range(L.rdm_net_num_backward_stages()):        # ~25 MB of gradients per stage: the DP exchange starts every few layers
             _lib.check(L.rdm_net_backward_stage(h, _lib.ptr(dlogits), table, gtable, C.c_void_p(self._ws.data_ptr()), ws_bytes, stage, st))
             if self.grad_ready_hook is not None:
