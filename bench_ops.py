@@ -60,7 +60,8 @@ def main():
     Rf = R.float()
     t = timeit(lambda: cp.als_pages(Rf, limit=100), reps=10)
     comp = Rf.numel() * 4 + 1024 * 256 * 4
-    report("als_rank1 d_10 B=16 (1024 matrices, 100 iters) - compulsory bytes", t, comp, "R read once (LDS-resident), p written; + iterate history 1024x101x256x4 B")
+    report("als_rank1 d_10 B=16 (1024 matrices, 100 iters) - compulsory bytes", t, comp,
+           "R read once (register-resident), p written; two passes: squared errors + the first 8 iterates recorded (8 MB instead of the 106 MB full history), a late arg-min is replayed")
     report("als_rank1 d_10 B=16 - streaming model of the reference algorithm", t, 301 * 65536 * 1024, "3 passes over R per iteration + 1 (SURVEY 8(d)): the reference's own traffic, never issued here")
     t = timeit(lambda: cp.als_pages(R, limit=100), reps=10)
     report("als_rank1 d_10 B=16, float64 grid input", t, R.numel() * 8 + 1024 * 256 * 4, "as Ordinal_Layer.forward feeds it (f64 grid -> f32 in LDS)")
@@ -78,6 +79,48 @@ def main():
     t = timeit(lambda: cp.dorn_ordinal_regression(lg))
     report("dorn_fwd B=16 8x10", t, lg.numel() * 4 + lg.numel() // 2 * 8 + B * 80 * 8, "latency-bound (1.5 MB)")
     bench_input_pipeline(dev)
+    bench_relative_decoder(dev)
+
+
+def bench_relative_decoder(dev, B=16):
+    """the WSM convolutions of the d_10 decoder at full width (RDM_Net.py:163-236, WSM_4: 208 channels at
+    128x128) as fp32-MFMA conv launches with their fraction of the 157.3 TFLOP/s peak, and the whole d_10 head (64 paged ratio
+    grids -> Lloyd -> rank-1 ALS -> reconstruct) as one figure."""
+    import ctypes as C
+    from md_rdm_amd._lib import ConvDesc
+    L = _lib.lib()
+    PEAK = 157.3
+
+    def conv_line(name, Bn, H, W, cin, cout, kh, kw, ph, pw, note):
+        cin_p, cout_p = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+        x = torch.randn(Bn, H, W, cin_p, device=dev)
+        wp = torch.randn(kh * kw, cout_p, cin_p, device=dev) * 0.02
+        Ho, Wo = H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+        y = torch.empty(Bn, Ho, Wo, cout_p, device=dev)
+        d = ConvDesc(Bn, H, W, cin_p, cin_p, cout_p, cout_p, kh, kw, 1, 1, ph, pw)
+        t = timeit(lambda: _lib.check(L.rdm_conv2d_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(wp), None, None, None, _lib.ptr(y), None, None, _lib.stream())), reps=10)
+        fl = 2.0 * Bn * Ho * Wo * cout * cin * kh * kw            # algorithmic (unpadded) FLOPs
+        print(json.dumps({"kernel": name, "ms": round(t * 1e3, 4), "algorithmic_GFLOP": round(fl / 1e9, 2), "achieved_TFLOPs": round(fl / t / 1e12, 1),
+                          "mfma_peak_TFLOPs": PEAK, "frac": round(fl / t / 1e12 / PEAK, 4), "note": note}), flush=True)
+
+    conv_line("WSM_4 conv2_2 5x5 52->52 @128x128 B=16 (d_10)", B, 128, 128, 52, 52, 5, 5, 2, 2, "the largest WSM conv by MACs per image at d_10 (RDM_Net.py:176); 52 channels pad to 64")
+    conv_line("WSM_1 conv2_2 5x5 416->416 @16x16 B=16 (d_7..d_10)", B, 16, 16, 416, 416, 5, 5, 2, 2, "the widest 5x5 (WSM_1, 1664/4 channels)")
+    conv_line("WSM_4 conv2_1 3x3 52->52 @128x128 B=16", B, 128, 128, 52, 52, 3, 3, 1, 1, "RDM_Net.py:175")
+    conv_line("WSM_4 input_adjustment 1x1 416->208 @64x64 B=16", B, 64, 64, 416, 208, 1, 1, 0, 0, "RDM_Net.py:186")
+    conv_line("WSM_4 deconv as 1x1 208->4x208 @64x64 B=16", B, 64, 64, 208, 4 * 208, 1, 1, 0, 0, "ConvTranspose2d(k=2,s=2) = 1x1 conv to 4 phases + pixel shuffle (:169)")
+    conv_line("WSM_4 strip (3,128) conv 26->26 as (3,1) over rows-as-channels B=16", B, 128, 1, 128 * 32, 26, 3, 1, 1, 0, "one conv per row: K = 128 pixels x 32 (padded 26) channels x 3 (:181-184)")
+    # the whole d_10 head on a (B,1,128,128) feature map
+    quant = RDM_Net.Quantization()
+    head = RDM_Net.Ordinal_Layer(10, False, quant)
+    feat = torch.from_numpy(filler.log_uniform("bo.feat", (B, 1, 128, 128), 0.8, 1.25)).to(dev)
+    with torch.no_grad():
+        t = timeit(lambda: head(feat), reps=10)
+    grid_bytes = 64 * B * 256 * 64 * 8
+    print(json.dumps({"kernel": "d_10 head B=16: resize 128->64 + 64 paged ratio grids + Lloyd(128 table) + ALS(100) + reconstruct", "ms": round(t * 1e3, 4),
+                      "maps_per_s": round(B / t, 1), "algorithmic_MB": round((grid_bytes * 2 + B * 128 * 128 * 8) / 1e6, 1),
+                      "achieved_GBps": round((grid_bytes * 2 + B * 128 * 128 * 8) / t / 1e9, 1), "hbm_peak_GBps": 8000.0,
+                      "frac": round((grid_bytes * 2 + B * 128 * 128 * 8) / t / 1e9 / 8000.0, 4),
+                      "note": "compulsory: the f64 grid written once and read once by the ALS (134 MB each way) + maps; the reference spends minutes here in Python loops (SURVEY 3.4)"}), flush=True)
 
 
 def bench_input_pipeline(dev, B=16, H=480, W=640):

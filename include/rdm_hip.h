@@ -201,6 +201,10 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 int rdm_net_forward(rdm_net* net, const float* x_nchw, void* const* tensors, void* workspace, size_t workspace_bytes,
                     float* logits_nchw, int32_t training, rdm_stream_t stream);
 
+/* The encoder output (trans_e4, RDM_Net.py:94: what every decoder consumes, :103-125) of the last rdm_net_forward on `workspace`,
+ * copied out as (B,1056,h,w) float32 NCHW - the input of the relative decoders d_6..d_10 (:57-61,106-125). */
+int rdm_net_encoder_output(const rdm_net* net, const void* workspace, size_t workspace_bytes, float* out_nchw, rdm_stream_t stream);
+
 /* Reduced-precision forward (BASELINE config 2, "batch=8 forward-only bf16"; the reference's default precision is mixed,
  * train.py:11,57-58): bf16 weights and activations in HBM, v_mfma_f32_16x16x32_bf16 with f32 accumulation, eval-mode BatchNorm
  * (running statistics) applied in f32 inside the conv staging, f32 bias and f32 logits.  Inference only: no statistics update, no
@@ -314,7 +318,8 @@ int rdm_ratio_grid_lloyd_dense(const float* d, float* R, int32_t batch, int32_t 
 int rdm_ratio_grid_lloyd_paged(const float* dn, const double* dn_1, double* R, int32_t batch, int32_t s, const double* quant40,
                                const double* inv41, int32_t quantize, rdm_stream_t stream);
 /* rank-1 ALS on `groups` independent calls of `batch` matrices (rows x cols, f64 or f32 input):
- * p (groups,batch,rows) f32 = first-arg-min-rmse iterate / gm; rmse (groups, limit+1) f32 scratch */
+ * p (groups,batch,rows) f32 = first-arg-min-rmse iterate / gm.  Two passes, no iterate history: all iterations record the squared error
+ * (and the first 8 iterates); a winner beyond those is recomputed by re-running that group to k* (same operations, same bits). */
 size_t rdm_als_workspace_bytes(int32_t groups, int32_t batch, int32_t rows, int32_t cols, int32_t limit);
 int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups, int32_t batch, int32_t rows, int32_t cols,
                   int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream);

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "rdm_net_set_option": (C.c_int, [vp, i32, i32]),
     "rdm_net_output_hw": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "rdm_net_forward": (C.c_int, [vp, vp, C.POINTER(vp), vp, sz, vp, i32, vp]),
+    "rdm_net_encoder_output": (C.c_int, [vp, vp, sz, vp, vp]),
     "rdm_net_bf16_weight_bytes": (sz, [vp]),
     "rdm_net_bf16_workspace_bytes": (sz, [vp]),
     "rdm_net_bf16_forward_bytes": (f64, [vp]),

@@ -644,6 +644,16 @@ int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, 
   return RDM_ERR_BAD_ARGUMENT;
 }
 
+/* the encoder's output (trans_e4, RDM_Net.py:94) of the last rdm_net_forward on this workspace, as (B,1056,h,w) float32 NCHW: the tensor
+ * every decoder of the reference consumes (:103-125).  It lives in the first 1056 channels of the decoder block's NHWC buffer. */
+int rdm_net_encoder_output(const rdm_net* net, const void* ws, size_t ws_bytes, float* out_nchw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(net && ws && out_nchw, "NULL argument");
+  const NetImpl& n = *reinterpret_cast<const NetImpl*>(net);
+  if (ws_bytes < n.total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  const BlockGeom& g = n.bg[3];
+  return launch_nhwc_to_nchw(reinterpret_cast<const float*>(static_cast<const char*>(ws) + n.blk[3]), g.ctot, out_nchw, n.B, kBlocks[3].cin, g.H * g.W, stream);
+}
+
 double rdm_net_forward_flops(const rdm_net* net) {
   if (!net) return 0;
   const NetImpl* n = reinterpret_cast<const NetImpl*>(net);

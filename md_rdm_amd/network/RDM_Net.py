@@ -179,6 +179,7 @@ def _dense_block_forward(block, x, training):
     one NHWC buffer holds all channels (concat-free), every conv is ``rdm_conv2d_fwd`` with the consumer's BN-ReLU as
     prologue and the next BatchNorm's channel statistics as epilogue.  No autograd (the reference's Lloyd step severs
     the graph above these decoders anyway, RDM_Net.py:296-297).  x (B,C,H,W) -> (B,H,W,C + 48*layers) NHWC."""
+    from . import wsm as _wsm
     L = _lib.lib()
     B, cin0, H, W = x.shape
     layers = list(block.children())
@@ -196,7 +197,6 @@ def _dense_block_forward(block, x, training):
     Y = torch.empty(M, cb, dtype=torch.float32, device=dev)
     ysum = torch.zeros(cb, dtype=torch.float64, device=dev)
     ysq = torch.zeros(cb, dtype=torch.float64, device=dev)
-    wp = torch.empty(9, GROWTH, cb, dtype=torch.float32, device=dev)
     st = _lib.stream()
     for i, lay in enumerate(layers):
         cin = cin0 + i * GROWTH
@@ -207,7 +207,7 @@ def _dense_block_forward(block, x, training):
         _lib.check(L.rdm_conv2d_fwd(C.byref(d1), _lib.ptr(blk), _lib.ptr(lay.conv1.weight.detach().contiguous()), None, _lib.ptr(sc1), _lib.ptr(sh1),
                                     _lib.ptr(Y), _lib.ptr(ysum), _lib.ptr(ysq), st))
         sc2, sh2 = _bn_affine(lay.norm2, ysum, ysq, M, training)
-        _lib.check(L.rdm_pack_conv_weight(_lib.ptr(lay.conv2.weight.detach().contiguous()), _lib.ptr(wp), GROWTH, cb, 3, 3, GROWTH, st))
+        wp, _, _ = _wsm._packed_cached(lay.conv2, ("dense3x3",), (lay.conv2.weight,), lambda lay=lay: (lay.conv2.weight.detach(), None, 3, 3))   # packed once, not per call
         d2 = _lib.ConvDesc(B, H, W, cb, cb, GROWTH, ctot, 3, 3, 1, 1, 1, 1)
         _lib.check(L.rdm_conv2d_fwd(C.byref(d2), _lib.ptr(Y), _lib.ptr(wp), None, _lib.ptr(sc2), _lib.ptr(sh2), C.c_void_p(blk.data_ptr() + 4 * cin),
                                     C.c_void_p(ssum.data_ptr() + 8 * cin), C.c_void_p(ssq.data_ptr() + 8 * cin), st))
@@ -216,7 +216,8 @@ def _dense_block_forward(block, x, training):
 
 class Decoder(nn.Module):
     """RDM_Net.py:137-162.  id 1 (the only decoder the reference instantiates) runs inside the native plan; ids 6..9 are the
-    relative decoders of SURVEY.md 8(f)4: dense block -> WSM chain -> conv1 -> ratio grid / Lloyd / ALS head, forward only."""
+    relative decoders of SURVEY.md 8(f)4 (d_10, :61, included): dense block -> WSM chain -> conv1 -> ratio grid / Lloyd / ALS head,
+    forward only, every derived (padded / packed) weight built once and reused until its parameter changes."""
 
     def __init__(self, in_channels, num_wsm_layers, DORN, id, quant):
         super().__init__()
@@ -295,8 +296,8 @@ class DepthEstimationNet(BaseModel):
     """Drop-in for the reference class (RDM_Net.py:25-135)."""
 
     def __init__(self, relative_decoders=()):
-        """``relative_decoders``: () = the reference's live graph (d_1 only).  A subset of (6, 7, 8, 9) adds the relative
-        decoders the reference keeps commented out (RDM_Net.py:57-60,106-125) with the reference's own
+        """``relative_decoders``: () = the reference's live graph (d_1 only).  A subset of (6, 7, 8, 9, 10) adds the relative
+        decoders the reference keeps commented out (RDM_Net.py:57-61,106-125) with the reference's own
         module names, so a checkpoint of the uncommented model loads; they run forward-only (see ``Decoder``)."""
         super().__init__()
         self.quantizers = Quantization()
@@ -305,8 +306,8 @@ class DepthEstimationNet(BaseModel):
             self.freeze_encoder()
         self.d_1 = Decoder(in_channels=1056, num_wsm_layers=0, DORN=True, id=1, quant=self.quantizers)
         self.relative_ids = tuple(sorted(set(int(d) for d in relative_decoders)))
-        if not set(self.relative_ids) <= {6, 7, 8, 9}:
-            raise ValueError("relative_decoders must be a subset of (6, 7, 8, 9), got %r" % (relative_decoders,))
+        if not set(self.relative_ids) <= {6, 7, 8, 9, 10}:
+            raise ValueError("relative_decoders must be a subset of (6, 7, 8, 9, 10), got %r" % (relative_decoders,))
         sizes = [1, 1, 1, 1, 0, 0, 0, 0]                       # candidates per pyramid level: d_1 gives levels 0..3,
         for did in self.relative_ids:                           # d_k (map side 2^(k-3)) gives F_1..F_(k-3) (relative_map drops d_0)
             setattr(self, "d_%d" % did, Decoder(in_channels=1056, num_wsm_layers=did - 6, DORN=False, id=did, quant=self.quantizers))
@@ -413,6 +414,7 @@ class DepthEstimationNet(BaseModel):
         self._ws_generation += 1
         _lib.check(L.rdm_net_forward(h, _lib.ptr(x), table, C.c_void_p(self._ws.data_ptr()), ws_bytes, _lib.ptr(logits), int(self.training), _lib.stream()))
         self._last = (h, ws_bytes, table, tensors)
+        self._last_batch = B
         return logits
 
     def _native_backward(self, dlogits):
@@ -502,6 +504,15 @@ class DepthEstimationNet(BaseModel):
                                           ws_bytes, _lib.ptr(logits), _lib.stream()))
         return logits
 
+    def encoder_output(self):
+        """(B,1056,h,w) float32: the encoder output (trans_e4, RDM_Net.py:94) of the last f32 forward - what every decoder consumes."""
+        h, ws_bytes, _, _ = self._last
+        B = self._last_batch
+        _, _, oh, ow = next(v for k, v in self._plans.items() if v[0] is h)
+        out = torch.empty(B, 1056, oh, ow, dtype=torch.float32, device=self._ws.device)
+        _lib.check(_lib.lib().rdm_net_encoder_output(h, C.c_void_p(self._ws.data_ptr()), ws_bytes, _lib.ptr(out), _lib.stream()))
+        return out
+
     def debug_buffer(self, name):
         """Float view of a named internal buffer of the last forward's plan (tests / debugging)."""
         h = self._last[0]
@@ -549,7 +560,7 @@ class DepthEstimationNet(BaseModel):
             if (H, W) != (8, 8):
                 raise _lib.RdmError("the relative decoders need the square 8x8 encoder output (226/228-pixel inputs), got %dx%d" % (H, W))
             with torch.no_grad():
-                enc = self.debug_buffer("blk3").view(B, H, W, -1)[..., :1056].permute(0, 3, 1, 2)   # trans_e4 output, still in the plan's block buffer
+                enc = self.encoder_output()                                      # trans_e4 output (B,1056,8,8) of the forward above
                 for did in self.relative_ids:
                     x_dk = getattr(self, "d_%d" % did)(enc)                      # (B,1,S,S) relative map, S = 2^(did-3)
                     rows.append(cp.decompose_depth_map([], x_dk, did - 3, relative_map=True)[::-1])

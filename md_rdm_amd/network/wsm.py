@@ -67,6 +67,34 @@ class _ConvNHWC(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+def _packed_cached(owner, key, params, build):
+    """Inference path: the padded + PACKED [tap][out][in] weight (and padded bias) of a conv is derived data - built once and
+    reused until one of ``params`` changes (tensor ``_version`` / storage), instead of a pad + pack launch on every call."""
+    sig = tuple((p._version, p.data_ptr()) for p in params if p is not None)
+    cache = owner.__dict__.setdefault("_rdm_packed", {})
+    hit = cache.get(key)
+    if hit is None or hit[0] != sig:
+        w, b, kh, kw = build()
+        Cout, Cin = w.shape[0], w.shape[1]
+        wp = torch.empty(kh * kw, Cout, Cin, device=w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rdm_pack_conv_weight(_lib.ptr(w.contiguous()), _lib.ptr(wp), Cout, Cin, kh, kw, Cout, _lib.stream()))
+        hit = (sig, wp, None if b is None else b.contiguous(), (Cout, Cin, kh, kw))
+        cache[key] = hit
+    return hit[1], hit[2], hit[3]
+
+
+def _conv_packed(x, wp, b, geom, ph, pw):
+    """forward-only conv on a pre-packed weight (no autograd node)"""
+    Cout, Cin, kh, kw = geom
+    B, H, W, _ = x.shape
+    x = x.contiguous()
+    y = torch.empty(B, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1, Cout, device=x.device, dtype=torch.float32)
+    d = ConvDesc(B, H, W, Cin, Cin, Cout, Cout, kh, kw, 1, 1, ph, pw)
+    _lib.check(_lib.lib().rdm_conv2d_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(b) if b is not None else None, None, None, _lib.ptr(y), None, None,
+                                         _lib.stream()))
+    return y
+
+
 def _padded(w, b, cin_p, cout_p):
     """zero-pad a (Cout,Cin,kh,kw) weight / (Cout,) bias to the 16-multiples the kernels contract over"""
     Cout, Cin = w.shape[0], w.shape[1]
@@ -83,6 +111,10 @@ def conv_nhwc(x, conv: nn.Conv2d, cin=None):
     ph, pw = conv.padding
     cin_p = x.shape[3]
     cout_p = _pad16(conv.out_channels)
+    if not torch.is_grad_enabled():                         # inference (the relative decoders): weights packed once
+        wp, b, geom = _packed_cached(conv, ("conv", cin_p), (conv.weight, conv.bias),
+                                     lambda: _padded(conv.weight.detach(), None if conv.bias is None else conv.bias.detach(), cin_p, cout_p) + (kh, kw))
+        return _conv_packed(x, wp, b, geom, ph, pw)
     w, b = _padded(conv.weight, conv.bias, cin_p, cout_p)
     return _ConvNHWC.apply(x, w, b, kh, kw, ph, pw)
 
@@ -127,10 +159,16 @@ class WSMLayer(nn.Module):
         cp = _pad16(Cc)
         B, H, W, cin_p = x.shape
         # weight (Cin, Cout, 2, 2) -> conv weight ((r,s,n), c, 1, 1) with each phase padded to cp
-        w = ct.weight.permute(2, 3, 1, 0)                                   # (2,2,Cout,Cin)
-        w = torch.nn.functional.pad(w, (0, cin_p - Cc, 0, cp - Cc)).reshape(4 * cp, cin_p, 1, 1)
-        b = torch.nn.functional.pad(ct.bias, (0, cp - Cc)).repeat(4)
-        y = _ConvNHWC.apply(x, w, b, 1, 1, 0, 0)                              # (B,H,W,4*cp)
+        def derived(wt, bt):
+            w = wt.permute(2, 3, 1, 0)                                       # (2,2,Cout,Cin)
+            w = torch.nn.functional.pad(w, (0, cin_p - Cc, 0, cp - Cc)).reshape(4 * cp, cin_p, 1, 1)
+            return w, torch.nn.functional.pad(bt, (0, cp - Cc)).repeat(4)
+        if not torch.is_grad_enabled():
+            wp, b, geom = _packed_cached(ct, ("deconv", cin_p), (ct.weight, ct.bias), lambda: derived(ct.weight.detach(), ct.bias.detach()) + (1, 1))
+            y = _conv_packed(x, wp, b, geom, 0, 0)
+        else:
+            w, b = derived(ct.weight, ct.bias)
+            y = _ConvNHWC.apply(x, w, b, 1, 1, 0, 0)                          # (B,H,W,4*cp)
         return y.view(B, H, W, 2, 2, cp).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cp)
 
     def _strip_rows(self, x, weight, bias):
@@ -140,9 +178,15 @@ class WSMLayer(nn.Module):
         n, c = weight.shape[0], weight.shape[1]
         assert W == weight.shape[3] and weight.shape[2] == 3, "WSM strip convs perform exactly one convolution per row"
         np_ = _pad16(n)
-        w = torch.nn.functional.pad(weight.permute(0, 3, 1, 2), (0, 0, 0, cpad - c))          # (n, k, cpad, 3)
-        w = w.reshape(n, W * cpad, 3, 1)
-        w, b = _padded(w, bias, W * cpad, np_)
+
+        def derived(wt, bt):
+            w = torch.nn.functional.pad(wt.permute(0, 3, 1, 2), (0, 0, 0, cpad - c))          # (n, k, cpad, 3)
+            return _padded(w.reshape(n, W * cpad, 3, 1), bt, W * cpad, np_)
+        if not torch.is_grad_enabled():
+            wp, b, geom = _packed_cached(self, ("strip", weight.data_ptr(), cpad), (weight, bias),
+                                         lambda: derived(weight.detach(), None if bias is None else bias.detach()) + (3, 1))
+            return _conv_packed(x.reshape(B, H, 1, W * cpad), wp, b, geom, 1, 0)
+        w, b = derived(weight, bias)
         return _ConvNHWC.apply(x.reshape(B, H, 1, W * cpad), w, b, 3, 1, 1, 0)               # (B,H,1,np_)
 
     def forward(self, x):

@@ -476,6 +476,28 @@ def run_rel_goldens(RDM, cp, out):
         n = int(np.log2(outm.shape[2]))
         rows.append(cp.decompose_depth_map([], outm, n, relative_map=True)[::-1])
         print(f"  d_{did}: feat {tuple(feat.shape)} out {tuple(outm.shape)} range [{float(outm.min()):.3f}, {float(outm.max()):.3f}]", flush=True)
+    # ---- d_10 (RDM_Net.py:61: four WSM layers, 208 channels at 128x128, 64 pages of 16x16) on its own: features and head -------
+    did = 10
+    torch.manual_seed(did)
+    dec = RDM.Decoder(in_channels=1056, num_wsm_layers=4, DORN=False, id=did, quant=quant)
+    sd = dec.state_dict()
+    for key, t in sd.items():
+        if t.numel() and t.dtype.is_floating_point:
+            t.copy_(tt(filler.state_value(f"d_{did}." + key, tuple(t.shape))))
+    with torch.no_grad():
+        dec.conv1.weight.mul_(0.02)
+        dec.conv1.bias.fill_(2.0)
+    dec.train()
+    with torch.no_grad():
+        h = dec.wsm_block(dec.dense_layer(x))
+        g["rel10_wsm_stats"] = stats3(h)
+        feat = dec.conv1(h)
+        g["rel10_feat_stats"] = stats3(feat)
+        g["rel10_feat_sub"] = feat[:, :, ::8, ::8].numpy()
+        outm = dec.ord_layer(feat.clone())
+    g["rel10_out"] = outm.numpy()
+    g["rel10_feat"] = feat.numpy().astype(np.float32)
+    print(f"  d_10: feat {tuple(feat.shape)} out {tuple(outm.shape)} range [{float(outm.min()):.3f}, {float(outm.max()):.3f}]", flush=True)
     g["rel_row_lens"] = np.array([len(r) for r in rows])
     y_hat = cp.relative_fine_detail_matrix(rows, False)
     g["rel_matrix_shapes"] = np.array([list(m.shape) for m in y_hat])

@@ -231,6 +231,26 @@ def test_als_quadratic_and_decoders(env, op_gold):
     np.testing.assert_allclose(RDM.Ordinal_Layer(8, False, quant)(g(d32, env)).cpu().numpy(), op_gold["d8_forward"], rtol=3e-5)
 
 
+def test_als_late_argmin_takes_the_replay_pass(env):
+    """rdm_als_rank1 keeps only the first 8 iterates (the full history was 106 MB at d_10 scale); an arg-min beyond them is served by
+    re-running the matrix to k*.  A symmetric 64x64 matrix makes the reference's "reinterpreted" q-update a true ALS step, so the
+    batch-global rmse keeps falling and k* lands late; the un-normalised winner must equal the oracle's."""
+    cp = env["cp"]
+    u = LU("als.sym.u", (2, 64, 1), 0.5, 2.0).astype(np.float64)
+    noise = U("als.sym.n", (2, 64, 64), -0.05, 0.05).astype(np.float64)
+    R = (u @ u.transpose(0, 2, 1) + 0.5 * (noise + noise.transpose(0, 2, 1))).astype(np.float32)
+    want, rmse = ocp.als_rank1(R, 3, 30, q_size=64)
+    kstar = int(np.argmin(rmse))
+    assert kstar > 8, kstar                                      # beyond the recorded iterates: exercises the replay kernel
+    got = cp.quadratic_als(g(R, env), cuda=True, n=3)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-5)
+    # and the common case (arg-min at the first update, served from the recorded iterates) in the same call pattern
+    Rq = LU("op.alsR8", (2, 64, 64), 0.5, 2.0)
+    want2, rmse2 = ocp.als_rank1(Rq, 3, 30, q_size=64)
+    assert int(np.argmin(rmse2)) <= 7
+    np.testing.assert_allclose(cp.quadratic_als(g(Rq, env), cuda=True, n=3).cpu().numpy(), want2, rtol=3e-5)
+
+
 def test_paging(env, op_gold):
     cp = env["cp"]
     d32 = LU("op.d32", (2, 1, 32, 32), 0.5, 2.0)
