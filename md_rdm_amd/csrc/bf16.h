@@ -21,6 +21,7 @@ struct Conv3Bf16Args {       // out[m][n] = sum_{tap,c} relu(Y[pix(m,tap)][c]*sc
   int B, H, W, M;
   float* partial; size_t partial_floats;   // optional f32 scratch for the K-split: [split][M][48] partial sums, reduced by a second (tiny) launch
   int split;                               // set by the launcher
+  int slots;                               // set by the launcher: zero-padded LDS image slots (pixels) the kernel may use, multiple of 8
   unsigned y_bytes, w_bytes, p_bytes;
 };
 

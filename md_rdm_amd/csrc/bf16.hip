@@ -74,7 +74,7 @@ __device__ __forceinline__ void xcd_order(int& bx, int& by) {      // see igemm.
 // Block = 4 wave64s (WM x WN), wave tile (MT*16 pixels) x (NT*16 channels), K walked in 64-deep steps (2 MFMA k-steps).
 // global -> registers (next step's loads in flight under this step's MFMAs) -> BN-ReLU -> swizzled LDS, 2 buffers, 1 barrier / step.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int BK, bool OUT_F32>
+template <int MT, int NT, int WM, int WN, int BK, int NS, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
   constexpr int CH = BK / 8, RP = 256 / CH;                          // 16-byte chunks per row; rows covered by one pass of the 256 threads
@@ -107,11 +107,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
     const int r = r0 + RP * i, n = n0 + r;
     woff[i] = (r < BN && n < p.N) ? (unsigned)n * (unsigned)(p.ldw * 2) + (unsigned)(ch * 16) : OOB;
   }
-  // Two register stages: the loads of step kt+2 are issued while step kt is multiplied, so every load has two full steps
-  // (2 x [MFMAs + LDS staging + barrier]) to land - with 16x the f32 MFMA rate a step is far shorter than an L2 / HBM round trip,
-  // and one stage of prefetch left the kernel waiting on memory latency (measured 0.6-1.5 us per 64-deep step).
+  // NS register stages: the loads of step k+NS are issued while step k is multiplied, so every load has NS full steps
+  // (NS x [MFMAs + LDS staging + barrier]) to land.  With 16x the f32 MFMA rate a 64-deep step of a small tile is ~300 cycles of
+  // work - far shorter than an L2 / HBM round trip - and a shallow prefetch leaves the kernel waiting on memory latency (measured
+  // ~1 us per step at M = 2280 whatever the tile).  Small tiles (few registers per stage) take 4 stages, 128 x 96 two.
   struct Stage { uint4 rx[XL]; uint4 rw[WL]; float4 sa, sb, ta, tb; };
-  Stage SA, SB;
+  Stage S[NS];
   auto load_step = [&](int kt, Stage& S) {
     const int k0 = kt * BK + ch * 8;
     const bool kok = k0 < p.K;                                        // K is a multiple of 8: a chunk is all in or all out
@@ -172,21 +173,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
   };
-  load_step(kbase, SA);
-  if (nk > 1) load_step(kbase + 1, SB);
-  store_step(0, SA);
-  if (nk > 2) load_step(kbase + 2, SA);
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+    if (u < nk) load_step(kbase + u, S[u]);                           // step j lives in stage j % NS
+  store_step(0, S[0]);
+  if (NS < nk) load_step(kbase + NS, S[0]);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    mma_step(0);                                                      // step kt (LDS buffer 0)
-    if (kt + 1 < nk) store_step(1, SB);                               // step kt+1, loaded one step ago
-    if (kt + 3 < nk) load_step(kbase + kt + 3, SB);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    mma_step(1);                                                      // step kt+1 (LDS buffer 1)
-    if (kt + 2 < nk) store_step(0, SA);
-    if (kt + 4 < nk) load_step(kbase + kt + 4, SA);
-    __syncthreads();
+  for (int kt = 0; kt < nk; kt += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int k = kt + u;                                           // the step multiplied now, in LDS buffer k & 1
+      if (k < nk) {
+        mma_step(k & 1);
+        if (k + 1 < nk) store_step((k + 1) & 1, S[(u + 1) % NS]);     // step k+1, loaded NS steps ago
+        if (k + 1 + NS < nk) load_step(kbase + k + 1 + NS, S[(u + 1) % NS]);
+        __syncthreads();
+      }
+    }
   }
   if (gridDim.z > 1) {                                                // partial sums -> this split's f32 slab (reduced in a fixed order by k_reduce_partials_bf16)
     float* slab = p.partial + (size_t)blockIdx.z * p.M * p.N;
@@ -225,21 +228,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 / 48 outputs on an LDS halo tile.  A block owns BM = MT*64 consecutive output pixels (linear NHWC
-// index).  Per 32-channel slab: ONE halo run of BM + 2(W+1) pixels (BN-ReLU applied once per element) and the 9 x 48 x 32
-// weight slab are staged; the 9 taps read their activation fragments from the run at pixel offset r*W + q, border / batch
-// wrap-around is undone with a 9-bit validity mask per lane row.  The next slab's global loads are in flight under the
+// 3x3 / stride 1 / pad 1 / 48 outputs on a zero-PADDED LDS image.  A block owns BM = MT*64 consecutive output pixels (linear
+// NHWC index).  Its input neighbourhood is staged as a 2-D image of padded rows: every image row gets a zero column on both
+// sides, every image a zero row above and below (padded row index = b*(H+2) + y + 1), so ALL nine taps of EVERY output pixel -
+// image borders and batch boundaries included - are plain reads at (row + r - 1, col + q - 1): no validity masks in the MFMA loop
+// (they were 6 VALU ops per fragment, 216 per slab, in a loop that is bound by instruction issue: 5.75 VALU per MFMA measured).
+// The pad slots are zeroed once per block and never written again; per 32-channel slab only the real pixels are loaded
+// (BN-ReLU applied once per element, in the staging registers) together with the 9 x 48 x 32 weight slab.  The LDS byte address of
+// every (m-tile, tap) fragment is computed once per block (9*MT VGPRs); the next slab's global loads are in flight under the
 // 9 x 3 x MT MFMAs of this one (register prefetch), 2 barriers per slab.
-// Dynamic LDS: [halo pixels][32] bf16 + [9*48][32] bf16.
+// Dynamic LDS: [padded rows x (W+2)][32] bf16 + [9*48][32] bf16.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int HL>      // HL >= ceil(halo pixels * 4 / 256): 16-byte halo chunks per thread and slab
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
+template <int MT, int HL>      // HL >= ceil(image slots * 4 / 256): 16-byte chunks per thread and slab
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   constexpr int BM = MT * 64, NT = 3, CS = 32, WLN = 7;              // 9*48*4 = 1728 weight chunks / 256 threads = 6.75
   extern __shared__ __attribute__((aligned(16))) unsigned short dyn[];
-  const int W = p.W, H = p.H;
-  const int halo = BM + 2 * (W + 1);
+  const int W = p.W, H = p.H, Wp = W + 2, Hp = H + 2;
   unsigned short* const Ah = dyn;
-  unsigned short* const Wl = dyn + (size_t)((halo + 7) & ~7) * CS;
+  unsigned short* const Wl = dyn + (size_t)p.slots * CS;              // p.slots: image slots the launcher sized the LDS for (multiple of 8)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
@@ -248,27 +254,46 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   const __amdgpu_buffer_rsrc_t srdY = srd(p.Y, p.y_bytes), srdW = srd(p.Wt, p.w_bytes);
   const __amdgpu_buffer_rsrc_t srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
 
-  unsigned vmask[MT];
+  auto prow_of = [&](int m, int& x) {                                 // padded row (global over the batch) and column of pixel m
+    const int hw = H * W, b = m / hw, rem = m - b * hw, y = rem / W;
+    x = rem - y * W;
+    return b * Hp + y + 1;
+  };
+  int xdummy;
+  const int m_last = min(p.M, m0 + BM) - 1;
+  const int pr_lo = prow_of(m0, xdummy) - 1, pr_hi = prow_of(m_last, xdummy) + 1;
+  const int nslots = (pr_hi - pr_lo + 1) * Wp;                        // <= p.slots (launcher bound)
+
+  // zero the image once: pad columns / rows (and out-of-batch rows) are never written afterwards
+  for (int i = tid; i < p.slots * (CS / 8); i += 256) *reinterpret_cast<uint4*>(Ah + i * 8) = make_uint4(0, 0, 0, 0);
+
+  // LDS byte address of the A fragment of (m-tile i, tap): slot of the lane's pixel shifted by (r-1, q-1), chunk g swizzled
+  unsigned faddr[MT][9];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wrow + i * 16 + l16;
-    unsigned v = 0;
-    if (m < p.M) {
-      const int hw = H * W, rem = m - (m / hw) * hw;
-      const int oy = rem / W, ox = rem - oy * W;
+    int x;
+    const int m = min(m0 + wrow + i * 16 + l16, p.M - 1);             // rows past M are never stored: any in-range address will do
+    const int sc = (prow_of(m, x) - pr_lo) * Wp + x + 1;
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        if ((unsigned)(oy + t / 3 - 1) < (unsigned)H && (unsigned)(ox + t % 3 - 1) < (unsigned)W) v |= 1u << t;
+    for (int t = 0; t < 9; ++t) {
+      const int sl = sc + (t / 3 - 1) * Wp + (t % 3 - 1);
+      faddr[i][t] = (unsigned)(sl * (CS * 2) + ((g ^ (((sl >> 2) & 1) << 1)) << 4));
     }
-    vmask[i] = v;
   }
   const int ch = tid & 3;                                             // chunk (8 channels) of the 32-channel slab, same for all of a thread's loads
-  unsigned hoff[HL];
+  unsigned hoff[HL], hlds[HL];
 #pragma unroll
   for (int i = 0; i < HL; ++i) {
-    const int hp = (tid + 256 * i) >> 2;
-    const long pix = (long)m0 - (W + 1) + hp;
-    hoff[i] = (hp < halo && pix >= 0 && pix < (long)p.M) ? (unsigned)pix * (unsigned)(p.ldy * 2) + (unsigned)(ch * 16) : OOB;
+    const int sl = (tid + 256 * i) >> 2;
+    hoff[i] = OOB; hlds[i] = 0;
+    if (sl < nslots) {
+      const int prow = sl / Wp, pcol = sl - prow * Wp, pr = pr_lo + prow;
+      const int b = pr / Hp, yy = pr - b * Hp - 1, x = pcol - 1;
+      if (pr >= 0 && b < p.B && (unsigned)yy < (unsigned)H && (unsigned)x < (unsigned)W) {
+        hoff[i] = (unsigned)((b * H + yy) * W + x) * (unsigned)(p.ldy * 2) + (unsigned)(ch * 16);
+        hlds[i] = (unsigned)(sl * CS + ((ch ^ (((sl >> 2) & 1) << 1)) << 3));
+      }
+    }
   }
   unsigned woff[WLN];
 #pragma unroll
@@ -293,10 +318,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   };
   auto store_slab = [&]() {
 #pragma unroll
-    for (int i = 0; i < HL; ++i) {
-      const int hp = (tid + 256 * i) >> 2;
-      if (hp < halo) *reinterpret_cast<uint4*>(Ah + hp * CS + ((ch ^ (((hp >> 2) & 1) << 1)) << 3)) = bnrelu8(rh[i], sa, sb, ta, tb);
-    }
+    for (int i = 0; i < HL; ++i)
+      if (hoff[i] != OOB) *reinterpret_cast<uint4*>(Ah + hlds[i]) = bnrelu8(rh[i], sa, sb, ta, tb);      // real pixels only: pads stay zero
 #pragma unroll
     for (int i = 0; i < WLN; ++i) {
       const int row = (tid + 256 * i) >> 2;
@@ -315,28 +338,21 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   const int per = (ncs_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int cs0 = blockIdx.y * per, ncs = min(ncs_all, cs0 + per);
   load_slab(cs0);
+  __syncthreads();                                                    // the zero fill is complete before the first real pixels land
   store_slab();
   __syncthreads();
   const int wsw = ((l16 >> 2) & 1) << 1;                              // weight rows of an n-tile start at a multiple of 16
+  const char* const AhB = reinterpret_cast<const char*>(Ah);
   for (int cs = cs0; cs < ncs; ++cs) {
     const bool more = cs + 1 < ncs;
     if (more) load_slab(cs + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int off = wrow + l16 + (tap / 3) * W + (tap % 3);         // halo[0] is pixel m0 - (W+1)
       bf16x8 wf[NT], xf[MT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wl + (tap * 48 + j * 16 + l16) * CS + ((g ^ wsw) << 3));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int hp = off + i * 16;
-        // (a wave-uniform "interior tile: skip the mask" branch was measured SLOWER, 243 vs 232 us on dense_e2: the scalar branches
-        // cut the unrolled tap loop into blocks the scheduler cannot interleave)
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ah + hp * CS + ((g ^ (((hp >> 2) & 1) << 1)) << 3));
-        const uint4 u = __builtin_bit_cast(uint4, v);
-        const unsigned keep = 0u - ((vmask[i] >> tap) & 1u);
-        xf[i] = __builtin_bit_cast(bf16x8, make_uint4(u.x & keep, u.y & keep, u.z & keep, u.w & keep));
-      }
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(AhB + faddr[i][tap]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -546,16 +562,18 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
     if (split < 1) split = 1;
     split = cdiv(nk64, cdiv(nk64, split));                                // no empty split
   }
-#define RDM_G(MT_, NT_, WM_, WN_, BK_)                                                                                                    \
+#define RDM_G(MT_, NT_, WM_, WN_, BK_, NS_)                                                                                               \
   do {                                                                                                                                      \
     dim3 grid(cdiv(a.N, NT_ * 16 * WN_), cdiv(a.M, MT_ * 16 * WM_), split);                                                                 \
-    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, true>), grid, dim3(256), 0, s, a);                           \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, false>), grid, dim3(256), 0, s, a);                                  \
+    if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, NS_, true>), grid, dim3(256), 0, s, a);                      \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, NS_, false>), grid, dim3(256), 0, s, a);                             \
   } while (0)
-  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64);
-  else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1, 64);
-  else if (a.M > 1024) RDM_G(1, 3, 4, 1, 64);                            // 64 x 48
-  else RDM_G(1, 3, 2, 2, 64);                                            // 32 x 96
+  // (measured at M = 2280: 64x48 / 64x96 / 128x48 / 128x96 tiles and 2 vs 4 register stages all land at 21-26 us - the kernel is
+  // bound by instruction issue, ~140 non-MFMA instructions per 64-deep step of which the BN-ReLU staging transform is the largest part)
+  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64, 2);
+  else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1, 64, 2);
+  else if (a.M > 1024) RDM_G(2, 3, 2, 2, 64, 2);                         // 64 x 96
+  else RDM_G(1, 3, 2, 2, 64, 2);                                         // 32 x 96
   if (split > 1) {
     const long mn4 = (long)a.M * a.N / 4;
     hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, a.N / 4,
@@ -578,14 +596,23 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
   // Tile and K-split.  Big pixel tiles stage the 27.6 KB weight slab once per 256 pixels (1.7x less L2 traffic per MFMA than
   // 128-pixel tiles); short grids are filled by splitting the channel slabs over grid.y (>= 2 slabs per split), partial sums go to
   // f32 slabs that one tiny launch reduces in a fixed order.  Target: 2-3 workgroups per CU.
-  const int bm = a.M >= 8192 ? 256 : a.M >= 4096 ? 128 : 64;
+  auto image_slots = [&](int bm_) {
+    // zero-padded LDS image: the tile's real rows (<= bm / W + 2 partial rows), one row above and below, and two pad rows for every
+    // image boundary the tile can straddle; each row W + 2 wide
+    const int rows = bm_ / a.W + 2 + 2 + 2 * (bm_ / (a.H * a.W) + 1);
+    return (rows * (a.W + 2) + 7) & ~7;
+  };
+  int bm = a.M >= 8192 ? 256 : a.M >= 4096 ? 128 : 64;
+  if (bm == 256 && cdiv(image_slots(256) * 4, 256) > 12) bm = 128;        // the 256-pixel kernel would spill with > 12 image chunks per thread (very wide rows)
   const int tiles = cdiv(a.M, bm), slabs = cdiv(a.C, 32);
   int split = 1;
   if (a.partial && tiles < 1024) {
     // Cost model in units of one slab of one block: time ~ rounds x (slabs per block + 2 for prologue / epilogue) + the reduction
-    // pass (split x M x 48 x 8 bytes at ~3 TB/s).  `slots` workgroups are resident at once (256 CUs x 2 at 256-pixel tiles
-    // [186 VGPRs], x 3 below): wave quantisation matters - a grid of 1.06 x slots runs as long as one of 2 x slots.
-    const int slots = 256 * (bm == 256 ? 2 : 3);
+    // pass (split x M x 48 x 8 bytes at ~3 TB/s).  `slots` workgroups are resident at once: wave quantisation matters - a grid of
+    // 1.06 x slots runs as long as one of 2 x slots.  (The first version of this kernel declared no minimum occupancy, the
+    // compiler parked 72 values in AGPRs, and ONE workgroup ran per CU: a time-vs-grid sweep, tools/bf16_occupancy_probe.py, shows it.)
+    const int hl_ = cdiv(image_slots(bm) * 4, 256);
+    const int slots = 256 * ((bm == 256 || hl_ > 6) ? 2 : 3);             // workgroups per CU: register-limited (see -Rpass-analysis: 2 or 3 waves per SIMD)
     const double t_slab = bm == 256 ? 2.5e-6 : bm == 128 ? 1.5e-6 : 1.0e-6;
     const double red = (double)a.M * 384.0 / 3e12 / t_slab;
     const long cap = std::min<long>(std::max(slabs / 2, 1), (long)(a.partial_floats / ((size_t)a.M * 48)));
@@ -598,11 +625,11 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
     }
   }
   a.split = split;
-  const int halo = bm + 2 * (a.W + 1);
-  const int hl = cdiv(halo * 4, 256);
-  RDM_CHECK_ARG(hl <= 16, "conv3x3_bf16: rows of %d pixels need a halo of %d pixels (> 1024)", a.W, halo);
-  const size_t ldsb = ((size_t)((halo + 7) & ~7) * 32 + 9 * 48 * 32) * 2;
-  RDM_CHECK_ARG(ldsb <= 160 * 1024, "conv3x3_bf16: halo tile of %zu bytes exceeds the 160 KB LDS", ldsb);
+  a.slots = image_slots(bm);
+  const int hl = cdiv(a.slots * 4, 256);
+  RDM_CHECK_ARG(hl <= 20, "conv3x3_bf16: rows of %d pixels need an LDS image of %d pixels (> 1280)", a.W, a.slots);
+  const size_t ldsb = ((size_t)a.slots * 32 + 9 * 48 * 32) * 2;
+  RDM_CHECK_ARG(ldsb <= 160 * 1024, "conv3x3_bf16: LDS image of %zu bytes exceeds the 160 KB LDS", ldsb);
   void* tk = profile_begin(s, 2.0 * a.M * 48.0 * a.C * 9.0, 8, 2.0 * ((double)a.M * a.C + 9.0 * 48 * a.C + (double)a.M * 48));
   dim3 grid(tiles, split);
 #define RDM_C3(MT_, HL_)                                                                                                                  \
@@ -612,8 +639,8 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
   } while (0)
 #define RDM_C3M(MT_)                                                          \
   do {                                                                        \
-    if (hl <= 3) RDM_C3(MT_, 3); else if (hl <= 4) RDM_C3(MT_, 4); else if (hl <= 5) RDM_C3(MT_, 5); else if (hl <= 7) RDM_C3(MT_, 7); \
-    else if (hl <= 10) RDM_C3(MT_, 10); else RDM_C3(MT_, 16);                \
+    if (hl <= 4) RDM_C3(MT_, 4); else if (hl <= 6) RDM_C3(MT_, 6); else if (hl <= 9) RDM_C3(MT_, 9); else if (hl <= 12) RDM_C3(MT_, 12); \
+    else RDM_C3(MT_, 20);                                                     \
   } while (0)
   if (bm == 256) RDM_C3M(4); else if (bm == 128) RDM_C3M(2); else RDM_C3M(1);
 #undef RDM_C3M
