@@ -1031,16 +1031,9 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     // few pixels (dense_e4, decoder): 128-pixel tiles double the workgroups before any split
     const bool small = a.M <= 8192 && 128 + 2 * (a.g.W + 1) <= 256 && g_variant != 21;
     const int bm = small ? 128 : 256;
+    // the split chosen above (for the generic tiling) is kept for 128-pixel tiles too: re-picking it for the doubled tile count
+    // was measured at whole-step level and lost (81.5 vs 79.0 ms/step at NYU B=16)
     int sp = split;
-    if (small && epi != EPI_STORE_STATS && !(epi == EPI_STORE && a.bias != nullptr) && !a.accumulate) {
-      sp = a.split_k > 0 ? a.split_k : pick_split_k((long)cdiv(a.N, 48) * cdiv(a.M, bm), kslabs, 256 * 4);
-      if (sp > 1 && split == 1) {                           // the generic path above decided against a split: zero the output now
-        epi = epi == EPI_MASK_STATS ? EPI_MASK_STATS_ATOMIC : EPI_ATOMIC;
-        if (int zrc = launch_zero_rows(a.out, a.M, a.N, a.ldc, s)) return zrc;
-      } else if (sp == 1 && split > 1) {
-        sp = split;                                          // output already zeroed and epilogue already atomic: keep a split
-      }
-    }
     if (sp > a.C / 16) sp = a.C / 16;
     dim3 grid(cdiv(a.N, 48), cdiv(a.M, bm), sp);
     const int hl = cdiv(bm + 2 * (a.g.W + 1), 64);           // 256-pixel tiles: 5 (W <= 31) .. 8 (<= 127); 128-pixel tiles: 3, 4

@@ -6,9 +6,9 @@ the C ABI of librdm_hip.so on the caller's HIP stream.  Tensors must live on the
 CPU path here (the CPU restatement lives in oracle/, for tests only).
 
 Pyramids ("lists of fine-detail maps") are produced by one kernel into ONE packed buffer; the list
-elements handed back are strided views of it, tagged so that downstream functions
-(relative_fine_detail_matrix -> make_pred -> recombination) can run fused single-launch kernels on
-the packed form.
+elements handed back are strided views of it, recognised again (through a registry of what such a view IS, see
+``_Pyramid``) by the downstream functions (relative_fine_detail_matrix -> make_pred -> recombination), which then run fused
+single-launch kernels on the packed form.
 """
 import ctypes as C
 import math
@@ -30,36 +30,59 @@ def _level_off(k):
 
 
 class _Pyramid:
-    """Packed per-sample pyramid [level0 (1x1) | level1 (2x2) | ...]; ``kind`` tracks what it holds."""
+    """Packed per-sample pyramid [level0 (1x1) | level1 (2x2) | ...]; ``kind`` tracks what it holds.
+    The reference hands pyramids around as Python lists of per-level tensors (computations.py:368-392, 423-484); the level views this
+    class gives out are recognised again by ``_pyramid_of`` through a REGISTRY keyed on what a view is - its storage, offset, shape
+    and the version counter of the packed buffer at creation - not through attributes hung on tensor objects: a list that was
+    re-assembled from views, detached or passed through ``list(...)`` is still recognised, while any in-place write to the packed
+    buffer (version bump) or any tensor that is not exactly such a view falls back to the general (unfused) path.
+    The registry is a small LRU that OWNS the pyramids it lists: while an entry exists its packed buffer is alive, so its address
+    cannot have been handed to another tensor (no false match); an evicted entry only costs the fused path, never correctness."""
 
-    def __init__(self, packed, n_levels, kind, first_level=0, source=None):
-        self.packed, self.n_levels, self.kind, self.first_level, self.source = packed, n_levels, kind, first_level, source
+    def __init__(self, packed, n_levels, kind, first_level=0, flat=False):
+        self.packed, self.n_levels, self.kind, self.first_level, self.flat = packed, n_levels, kind, first_level, flat
+        self.version = packed._version
+
+    def level_shape(self, k):
+        B, s = self.packed.shape[0], 1 << k
+        return (B, 1, s * s) if self.flat else (B, 1, s, s)
 
     def views(self):
-        B = self.packed.shape[0]
-        out = []
-        for k in range(self.first_level, self.n_levels):
-            s = 1 << k
-            v = self.packed[:, _level_off(k):_level_off(k + 1)].view(B, 1, s, s)
-            v._rdm_pyramid = (self, k)
-            out.append(v)
+        out = [self.packed[:, _level_off(k):_level_off(k + 1)].view(self.level_shape(k)) for k in range(self.first_level, self.n_levels)]
+        key = self._key(out[0])
+        _REGISTRY.pop(key, None)
+        _REGISTRY[key] = self
+        while len(_REGISTRY) > _REGISTRY_CAP:
+            _REGISTRY.pop(next(iter(_REGISTRY)))
         return out
+
+    @staticmethod
+    def _key(t):
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+
+_REGISTRY = {}                  # insertion-ordered: oldest first
+_REGISTRY_CAP = 8               # a training step makes three pyramids (target levels, their log form, the prediction)
 
 
 def _pyramid_of(tensors):
     """The packed pyramid behind a list of level views (ascending sizes), or None."""
-    if not tensors:
+    if not tensors or not isinstance(tensors[0], torch.Tensor):
         return None
-    tag = getattr(tensors[0], "_rdm_pyramid", None)
-    if tag is None:
+    pyr = _REGISTRY.get(_Pyramid._key(tensors[0]))
+    if pyr is None:
         return None
-    pyr, k0 = tag
-    for i, t in enumerate(tensors):
-        tg = getattr(t, "_rdm_pyramid", None)
-        if tg is None or tg[0] is not pyr or tg[1] != k0 + i:
+    if pyr.packed._version != pyr.version or len(tensors) != pyr.n_levels - pyr.first_level:
+        return None
+    base, es = pyr.packed.storage_offset(), pyr.packed.stride(0)
+    for i, t in enumerate(tensors):                                # every element must BE the corresponding level view
+        k = pyr.first_level + i
+        s = 1 << k
+        if (not isinstance(t, torch.Tensor) or t.dtype != pyr.packed.dtype or tuple(t.shape) != pyr.level_shape(k)
+                or t.untyped_storage().data_ptr() != pyr.packed.untyped_storage().data_ptr()
+                or t.storage_offset() != base + _level_off(k) or t.stride(0) != es or t.stride(-1) != 1
+                or (not pyr.flat and s > 1 and t.stride(2) != s)):
             return None
-    if k0 != pyr.first_level or len(tensors) != pyr.n_levels - pyr.first_level:
-        return None
     return pyr
 
 
@@ -140,14 +163,8 @@ def relative_fine_detail_matrix(fine_detail_rows, cuda):
     if len(fine_detail_rows) == 1:
         pyr = _pyramid_of(list(fine_detail_rows[0]))
         if pyr is not None and pyr.kind == "levels":
-            lp = _Pyramid(pyr.packed, pyr.n_levels, "log_pending", pyr.first_level)
-            B = pyr.packed.shape[0]
-            out = []
-            for v in lp.views():
-                m = v.view(B, 1, -1)
-                m._rdm_pyramid = v._rdm_pyramid
-                out.append(m)
-            return out
+            lp = _Pyramid(pyr.packed, pyr.n_levels, "log_pending", pyr.first_level, flat=True)   # same buffer, (B,1,HW) views: log + weighting pending
+            return lp.views()
     slots = [[] for _ in range(8)]
     for row in fine_detail_rows:
         for m in row:
