@@ -264,9 +264,17 @@ def bench_fwd_bf16(args):
         dom = per_kernel[0]
         bound = "mfma" if dom["mfma_frac"] >= dom["hbm_frac"] else "hbm"       # the roofline the dominant kernel sits closer to
         algo_fl = L.rdm_net_forward_flops(h)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hbm_traffic_bf16.json")
+        if os.path.exists(tpath) and (B, H, W) == (8, 228, 304):      # PMC passes cannot run inside this process: measured figures of the same workload
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            e = tj["kernels"].get(dom["kernel"].split(" ")[0])
+            if e:
+                traffic, traffic_src = e["traffic_bytes_per_launch"], "profiles/r02_hbm_traffic_bf16.json: " + tj["source"]
         roof = {"bound": bound, "kernel": dom["kernel"],
                 "achieved": dom["tflops"] if bound == "mfma" else dom["algorithmic_GBps"], "peak": PEAK_MFMA if bound == "mfma" else PEAK_HBM,
-                "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": dom["mfma_frac"] if bound == "mfma" else dom["hbm_frac"], "traffic": None,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": dom["mfma_frac"] if bound == "mfma" else dom["hbm_frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "per_kernel": per_kernel, "conv_kernel_ms_per_step": round(ms_sum.value / args.steps, 3), "conv_launches_per_step": n.value // args.steps,
                 "whole_stack": {"algorithmic_tflop_per_step": round(algo_fl / 1e12, 4), "algorithmic_GB_per_step": round(L.rdm_net_bf16_forward_bytes(h) / 1e9, 3),
                                 "stack_ms_per_step": round(stack_ms, 3), "mfma_frac": round(algo_fl / (stack_ms * 1e-3) / 1e12 / PEAK_MFMA, 4),
