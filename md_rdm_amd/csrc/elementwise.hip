@@ -8,6 +8,8 @@
 
 namespace rdm {
 
+extern int g_variant;
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
@@ -190,15 +192,26 @@ int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t 
 // four channels (a thread keeps its channel group and walks rows), then dst (=|+=) A*dz + B*x + Cc.
 // Removes a 4-us dependent launch from every BatchNorm of the backward chain (156 per step) - and with
 // it the stall of a tiny kernel queued behind the side stream's long-running wgrad blocks.
+//
+// This pass runs on the dependent chain WHILE the side stream's weight-gradient kernels own the chip (2 waves per SIMD at 219 VGPRs,
+// issue-bound): beside conv_wgrad3_row_kernel the first version took 1 260 us for dense_e2's 2.3 GB instead of 470 us alone, while a
+// plain float4 copy only went from 305 to 350 us (tools/coresidency_probe.py).  The difference is VALU instructions per byte - one
+// co-resident wave (<= 64 VGPRs fit beside the two) gets the issue slots the older waves leave over.  Hence: SRD buffer accesses with
+// the row advance in an SGPR offset (no vector address arithmetic at all), packed v_pk_fma_f32 (4 instead of 8 FMAs per float4),
+// x (1/count) instead of eight f64 divisions per thread, and half as many, longer workgroups.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+
 template <bool ACC>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0,
-                                                      const double* s1, double count, const float* gamma, const float* mean,
-                                                      const float* rstd, float* dgamma, float* dbeta, int M, int C4, int rows_per_block,
-                                                      int training) {
+__global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0,
+                                                         const double* s1, double inv_count, const float* gamma, const float* mean,
+                                                         const float* rstd, float* dgamma, float* dbeta, int M, int C4, int rows_per_block,
+                                                         int training, unsigned dst_bytes, unsigned dz_bytes, unsigned x_bytes) {
   const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);
   if (c4 >= C4) return;
   const int c = c4 * 4, rsub = threadIdx.x >> 6;
-  float a[4], b[4], cc[4], dg[4], db[4];
+  f32x2 a[2], b[2], cc[2];
+  float dg[4], db[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const double mu = mean[c + j], rs = rstd[c + j], g = gamma[c + j];
@@ -206,31 +219,61 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* dst, int ldd, const
     const double sdzxhat = rs * (sdzx - mu * sdz);
     dg[j] = (float)sdzxhat; db[j] = (float)sdz;
     const double aa = g * rs;
+    float fa = (float)aa, fb = 0.f, fc = 0.f;
     if (training) {
-      const double m1 = sdz / count, m2 = sdzxhat / count;
+      const double m1 = sdz * inv_count, m2 = sdzxhat * inv_count;
       const double bb = -aa * rs * m2;
-      a[j] = (float)aa; b[j] = (float)bb; cc[j] = (float)(-aa * m1 - bb * mu);
-    } else {
-      a[j] = (float)aa; b[j] = 0.f; cc[j] = 0.f;
+      fb = (float)bb; fc = (float)(-aa * m1 - bb * mu);
     }
+    a[j >> 1][j & 1] = fa; b[j >> 1][j & 1] = fb; cc[j >> 1][j & 1] = fc;
   }
   if (blockIdx.y == 0 && rsub == 0) {
     // scalar stores: parameter-gradient tensors are only 4-byte aligned in general
     if (dgamma) { dgamma[c] = dg[0]; dgamma[c + 1] = dg[1]; dgamma[c + 2] = dg[2]; dgamma[c + 3] = dg[3]; }
     if (dbeta) { dbeta[c] = db[0]; dbeta[c + 1] = db[1]; dbeta[c + 2] = db[2]; dbeta[c + 3] = db[3]; }
   }
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
   const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
-#pragma unroll 4
-  for (int m = m0 + rsub; m < m1; m += 4) {
-    const float4 z = ld4(dz + (long)m * ldz + c), xv = ld4(x + (long)m * ldx + c);
-    float4 r;
-    r.x = fmaf(a[0], z.x, fmaf(b[0], xv.x, cc[0]));
-    r.y = fmaf(a[1], z.y, fmaf(b[1], xv.y, cc[1]));
-    r.z = fmaf(a[2], z.z, fmaf(b[2], xv.z, cc[2]));
-    r.w = fmaf(a[3], z.w, fmaf(b[3], xv.w, cc[3]));
-    float* d = dst + (long)m * ldd + c;
-    if (ACC) { const float4 o = ld4(d); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-    st4(d, r);
+  // per-lane byte offsets of row (m0 + rsub); rows advance by 4 through the scalar offset.  All extents < 4 GiB (launcher).
+  const unsigned vz = ((unsigned)rsub * (unsigned)ldz + (unsigned)c) * 4u, vx = ((unsigned)rsub * (unsigned)ldx + (unsigned)c) * 4u,
+                 vd = ((unsigned)rsub * (unsigned)ldd + (unsigned)c) * 4u;
+  unsigned sz = (unsigned)m0 * (unsigned)ldz * 4u, sx = (unsigned)m0 * (unsigned)ldx * 4u, sd = (unsigned)m0 * (unsigned)ldd * 4u;
+  const unsigned dzs = (unsigned)ldz * 16u, dxs = (unsigned)ldx * 16u, dds = (unsigned)ldd * 16u;      // 4 rows
+  auto one = [&](u32x4e z, u32x4e xv, u32x4e o) {
+    f32x2 z0 = {__uint_as_float(z.x), __uint_as_float(z.y)}, z1 = {__uint_as_float(z.z), __uint_as_float(z.w)};
+    f32x2 x0 = {__uint_as_float(xv.x), __uint_as_float(xv.y)}, x1 = {__uint_as_float(xv.z), __uint_as_float(xv.w)};
+    f32x2 r0 = __builtin_elementwise_fma(a[0], z0, __builtin_elementwise_fma(b[0], x0, cc[0]));
+    f32x2 r1 = __builtin_elementwise_fma(a[1], z1, __builtin_elementwise_fma(b[1], x1, cc[1]));
+    if (ACC) {
+      r0 += (f32x2){__uint_as_float(o.x), __uint_as_float(o.y)};
+      r1 += (f32x2){__uint_as_float(o.z), __uint_as_float(o.w)};
+    }
+    u32x4e r = {__float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r1.x), __float_as_uint(r1.y)};
+    return r;
+  };
+  int m = m0;
+  for (; m + 16 <= m1; m += 16) {                                     // 4 row groups in flight; every lane's row is < m1 here
+    u32x4e z[4], xv[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[k] = __builtin_amdgcn_raw_buffer_load_b128(rz, (int)vz, (int)(sz + k * dzs), 0);
+      xv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vx, (int)(sx + k * dxs), 0);
+      if (ACC) o[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)vd, (int)(sd + k * dds), 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b128(one(z[k], xv[k], o[k]), rd, (int)vd, (int)(sd + k * dds), 0);
+    sz += 4 * dzs; sx += 4 * dxs; sd += 4 * dds;
+  }
+  for (; m < m1; m += 4) {                                            // tail: rows >= m1 belong to the next workgroup (or do not exist)
+    const bool ok = m + rsub < m1;
+    const u32x4e z = __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? (int)vz : -1, (int)sz, 0);
+    const u32x4e xv = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (int)vx : -1, (int)sx, 0);
+    u32x4e o = {0u, 0u, 0u, 0u};
+    if (ACC) o = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (int)vd : -1, (int)sd, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(one(z, xv, o), rd, ok ? (int)vd : -1, (int)sd, 0);
+    sz += dzs; sx += dxs; sd += dds;
   }
 }
 
@@ -238,11 +281,16 @@ int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const flo
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
                         int training, hipStream_t s) {
   const int C4 = C / 4, gx = cdiv(C4, 64);
-  int rpb = cdiv(M, std::max(1, 4096 / gx));
-  rpb = std::max(16, (rpb + 3) / 4 * 4);
+  const long eb[3] = {((long)(M - 1) * ldd + C) * 4, ((long)(M - 1) * ldz + C) * 4, ((long)(M - 1) * ldx + C) * 4};
+  if (eb[0] >= 0xFFFFFFFFL || eb[1] >= 0xFFFFFFFFL || eb[2] >= 0xFFFFFFFFL) {
+    set_error("bn_bwd: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing");
+    return RDM_ERR_UNSUPPORTED;
+  }
+  int rpb = cdiv(M, std::max(1, 2048 / gx));
+  rpb = std::max(16, (rpb + 15) / 16 * 16);
   dim3 grid(gx, cdiv(M, rpb));
-  if (accumulate) hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training);
-  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training);
+  if (accumulate) hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
+  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
   RDM_LAUNCH_OK();
   return 0;
 }

@@ -1,0 +1,51 @@
+"""How fast do HBM-streaming kernels run BESIDE the 3x3 weight-gradient kernel (dense_e2 shapes, B=16 228x304)?
+main stream: BatchNorm-backward apply pass / plain float4 copy; side stream: rdm_conv2d_wgrad 3x3 2736 -> 48 (conv_wgrad3_row_kernel)."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from md_rdm_amd import _lib
+L = _lib.lib()
+if os.environ.get("RDM_VARIANT"): L.rdm_debug_variant(int(os.environ["RDM_VARIANT"]))
+dev = torch.device("cuda:0")
+B, H, W, Cb = 16, 57, 76, 2736
+M = B * H * W
+x = torch.randn(M, Cb, device=dev); dz = torch.randn(M, Cb, device=dev); dx = torch.zeros(M, Cb, device=dev)
+dy = torch.randn(M, 48, device=dev); dw = torch.zeros(9 * 48 * Cb, device=dev)
+sc = torch.rand(Cb, device=dev) + 0.5; sh = torch.randn(Cb, device=dev) * 0.1
+s0 = torch.randn(Cb, device=dev, dtype=torch.float64); s1 = torch.randn(Cb, device=dev, dtype=torch.float64)
+g = torch.rand(Cb, device=dev) + 0.5; mu = torch.randn(Cb, device=dev); rs = torch.rand(Cb, device=dev) + 0.5
+dg = torch.empty(Cb, device=dev); db = torch.empty(Cb, device=dev)
+d3 = _lib.ConvDesc(B, H, W, Cb, Cb, 48, 48, 3, 3, 1, 1, 1, 1)
+side = torch.cuda.Stream()
+
+def wgrad3(stream):
+    _lib.check(L.rdm_conv2d_wgrad(C.byref(d3), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(dw), C.c_void_p(stream.cuda_stream)))
+def apply(stream):
+    _lib.check(L.rdm_bn_bwd(_lib.ptr(dx), Cb, _lib.ptr(dz), Cb, _lib.ptr(x), Cb, _lib.ptr(s0), _lib.ptr(s1), float(M), _lib.ptr(g), _lib.ptr(mu), _lib.ptr(rs),
+                            _lib.ptr(dg), _lib.ptr(db), M, Cb, 0, 1, C.c_void_p(stream.cuda_stream)))
+def copy(stream):
+    _lib.check(L.rdm_microbench_copy(_lib.ptr(dz), _lib.ptr(dx), M * Cb, C.c_void_p(stream.cuda_stream)))
+
+main = torch.cuda.current_stream()
+def timed(fn, beside):
+    best = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0e, s1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if beside:
+            s0e.record(side); wgrad3(side); s1e.record(side)
+            for _ in range(20000): pass                       # let the side kernel occupy the chip first
+        e0.record(main); fn(main); e1.record(main)
+        torch.cuda.synchronize()
+        best.append((e0.elapsed_time(e1) * 1e3, s0e.elapsed_time(s1e) * 1e3 if beside else 0.0))
+    best.sort()
+    return best[len(best) // 2]
+for _ in range(2): wgrad3(main); apply(main); copy(main)
+torch.cuda.synchronize()
+for name, fn, by in (("bn_bwd apply (norm2, 3 streams)", apply, 3 * M * Cb * 4), ("float4 copy (2 streams)", copy, 2 * M * Cb * 4)):
+    a = timed(fn, False); b = timed(fn, True)
+    print(f"{name}: alone {a[0]:7.1f} us ({by / a[0] / 1e6:5.2f} TB/s)   beside wgrad3_row {b[0]:7.1f} us ({by / b[0] / 1e6:5.2f} TB/s), wgrad3 took {b[1]:7.1f} us", flush=True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record(main); wgrad3(main); e1.record(main); torch.cuda.synchronize()
+print(f"wgrad3_row alone: {e0.elapsed_time(e1) * 1e3:7.1f} us")
