@@ -56,7 +56,9 @@ double rdm_profile_kind_bytes(int32_t kind);
 /* development switch for in-process A/B timing of the measured alternatives DESIGN.md 4.1 cites (0 = shipped):
  * 7 generic instead of halo 3x3, 8 no forward pipelining, 9 generic instead of row wgrad, 11 hardware block order,
  * 13 128x96 wgrad tiles only, 14 default-priority side stream, 16/20 256x48 tiles on 1x1 convs, 21 256-pixel halo tiles only,
- * 23 full-size wgrad tiles at small M, 26 hand-pipelined (251-VGPR) row wgrad.  Results never depend on it beyond float rounding. */
+ * 23 full-size wgrad tiles at small M, 26 hand-pipelined (251-VGPR) row wgrad.  Results never depend on it beyond float rounding.
+ * It exists only in libraries built with RDM_DEV_VARIANTS=1; the shipped build compiles the alternatives out (the switch is a
+ * compile-time 0, no launcher reads mutable global state) and this call reports an error for v != 0. */
 void rdm_debug_variant(int32_t v);
 /* number of kernel-launching calls the library has made in this process (monotonic; bench.py reports the per-step difference;
  * a K-split launcher that also enqueues its zero-fill or reduction counts once per enqueued kernel family) */

@@ -23,8 +23,15 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    """RDM_DEV_VARIANTS=1 in the environment compiles the development A/B switch in (rdm_debug_variant); the default ("ship") build has
+    none.  Switching mode rebuilds everything."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    mode = "dev" if os.environ.get("RDM_DEV_VARIANTS", "0") not in ("", "0") else "ship"
+    stamp = os.path.join(OBJ, ".mode")
+    if not os.path.exists(stamp) or open(stamp).read().strip() != mode:
+        force = True
+    flags = FLAGS + (["-DRDM_DEV_VARIANTS"] if mode == "dev" else [])
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "rdm_hip.h")]
     jobs = []
     for src in sources():
@@ -34,7 +41,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -51,7 +58,9 @@ def build(force=False, verbose=True):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
         if verbose:
-            print(f"[build] linked {LIB}", flush=True)
+            print(f"[build] linked {LIB} ({mode})", flush=True)
+    with open(stamp, "w") as fh:
+        fh.write(mode)
     return LIB
 
 

@@ -8,7 +8,6 @@
 #include "bf16.h"
 
 namespace rdm {
-extern int g_variant;
 long long g_launches = 0;
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -37,7 +36,16 @@ extern "C" {
 const char* rdm_last_error_string(void) { return g_err; }
 int rdm_version(void) { return 100; }
 
-void rdm_debug_variant(int32_t v) { rdm::g_variant = v; }
+void rdm_debug_variant(int32_t v) {
+#ifdef RDM_DEV_VARIANTS
+  rdm::g_variant = v;
+#else
+  if (v != 0) {
+    rdm::set_error("rdm_debug_variant(%d): this library was built without RDM_DEV_VARIANTS - the shipped configuration is the only one", (int)v);
+    fprintf(stderr, "[librdm_hip] rdm_debug_variant(%d) ignored: built without RDM_DEV_VARIANTS\n", (int)v);
+  }
+#endif
+}
 int64_t rdm_launch_count(void) { return rdm::g_launches; }
 void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches) {

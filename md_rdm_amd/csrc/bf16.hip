@@ -30,7 +30,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0xFFFFFFFFu;
-extern int g_variant;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t srd(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);

@@ -930,7 +930,9 @@ int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
+#ifdef RDM_DEV_VARIANTS
 int g_variant = 0;      // A/B switch for in-process kernel comparisons (rdm_debug_variant)
+#endif
 
 int pick_split_k(long tiles, long kslabs, int slots) {
   // `slots` = workgroups resident on the chip at once (256 CUs x blocks/CU).  The grid runs in

@@ -21,7 +21,6 @@
 
 namespace rdm {
 
-extern int g_variant;
 
 namespace {
 

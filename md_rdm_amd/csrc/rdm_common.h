@@ -40,6 +40,15 @@ extern long long g_launches;
     }                                                                                 \
   } while (0)
 
+// Development A/B switch behind rdm_debug_variant (the measured alternatives DESIGN.md cites).  It exists only in builds made with
+// RDM_DEV_VARIANTS=1 (`RDM_DEV_VARIANTS=1 python -m md_rdm_amd.build`); in the shipped library it is the constant 0, every
+// `g_variant == N` branch folds away at compile time and no launcher reads mutable process-wide state.
+#ifdef RDM_DEV_VARIANTS
+extern int g_variant;
+#else
+constexpr int g_variant = 0;
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------
