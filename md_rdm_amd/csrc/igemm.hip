@@ -90,13 +90,24 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
 // adjacent in time on one XCD are adjacent column tiles of the same row-tile.  A bijection for any
 // grid size; placement only affects speed, never results.  A/B on dense_e2: 1x1 dgrad 116.6 vs 109.7 TFLOP/s.
 // ---------------------------------------------------------------------------------------------
+// flat: 0 = XCD-aware, 1 = hardware order, G >= 2 = XCD-aware AND row-grouped: inside an XCD's range the tiles are walked in groups
+// of G row-tiles, column by column (G blocks in a row share one WEIGHT tile, the group's G activation tiles stay in L2 across all
+// columns).  For the 3x3 dgrad of dense_e2 (57 column tiles x 83 KB of weights = 4.7 MB, more than one L2 holds) the plain order
+// streams every weight tile once per ROW tile: 1.22 GB of L2 fills per launch against 18 MB of operands (tools/fetch_calibration.py).
 __device__ __forceinline__ void xcd_block_order(int flat, int& bx, int& by, int& bz) {
   bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-  if (flat) return;
+  if (flat == 1) return;
   const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
   const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
   const unsigned x = L & 7u, seq = L >> 3, q = total >> 3, r = total & 7u;
   const unsigned Lp = x * q + (x < r ? x : r) + seq;
+  if (flat >= 2 && gridDim.z == 1) {
+    const unsigned G = (unsigned)flat, gsz = G * gx, grp = Lp / gsz, rem = Lp - grp * gsz;
+    const unsigned rows = min(G, gy - grp * G);                       // the last group may be short
+    const unsigned c = rem / rows;
+    bx = (int)c; by = (int)(grp * G + (rem - c * rows)); bz = 0;
+    return;
+  }
   bx = (int)(Lp % gx);
   const unsigned t = Lp / gx;
   by = (int)(t % gy); bz = (int)(t / gy);
@@ -1037,6 +1048,14 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     // was measured at whole-step level and lost (81.5 vs 79.0 ms/step at NYU B=16)
     int sp = split;
     if (sp > a.C / 16) sp = a.C / 16;
+    {
+      // row-grouped block order (xcd_block_order) when the weights of all column tiles do not stay in one 4 MB L2 but a group of
+      // 8 activation (halo) tiles does: dense_e2's dgrad, 57 column tiles x 83 KB.  Measured there (rocprofv3 FETCH_SIZE, calibrated:
+      // tools/fetch_calibration.py): L2 fills of the main loop 1.22 GB -> 0.18 GB per launch, whole kernel 2.55x -> 1.21x its
+      // compulsory bytes; the time does not move (1.468 ms either way - the kernel is bound by instruction issue, not by the fabric).
+      const double w_total = (double)a.N * 9.0 * a.C * 4.0, a_tile = (double)(bm + 2 * (a.g.W + 1)) * a.C * 4.0;
+      if (!a.xcd_flat && sp == 1 && g_variant != 29 && w_total > 2.5e6 && 8.0 * a_tile <= 2.0e6) a.xcd_flat = 8;
+    }
     dim3 grid(cdiv(a.N, 48), cdiv(a.M, bm), sp);
     const int hl = cdiv(bm + 2 * (a.g.W + 1), 64);           // 256-pixel tiles: 5 (W <= 31) .. 8 (<= 127); 128-pixel tiles: 3, 4
 #define RDM_HALO2(E_, D_)                                                                                       \
