@@ -140,7 +140,7 @@ def main():
         # driver-timed whole-step figure are given next to it.
         dom = per_kernel[0]
         traffic, traffic_src, fam_traffic = None, None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath) and (B, H, W) == (16, 228, 304):     # PMC passes cannot run inside this process: measured figures of the same workload
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -150,7 +150,7 @@ def main():
                 if key in e["kernel"]:
                     traffic = round((2 * e["fetch_raw_bytes_per_step"] + e["write_bytes_per_step"]) / e["launches_per_step"])
                     break
-            traffic_src = ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 "
+            traffic_src = ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 "
                            "correction, checked on k_adamw), bytes per launch of this kernel averaged over one step")
         step_frac = algo / args.steps / (elapsed / args.steps) / 1e12 / peak
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
