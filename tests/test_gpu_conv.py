@@ -95,6 +95,38 @@ def test_conv_family(case):
             assert rel(s1.cpu(), (refm.double() * xin.double()).sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 2736), (144, 200), (336, 208), (48, 96)])
+def test_conv1x1_big_grid(cin, cout):
+    """The big-grid 1x1 forward (>= 32 768 pixels, dense_e2's regime) vs an f64 matmul: K a multiple of 32 and with a 16-channel tail,
+    ragged M and N tiles, the BN-ReLU prologue, the statistics epilogue - and NaN in the channels BEHIND the contracted prefix of the
+    input buffer (nothing beyond K may ever reach an accumulator)."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, ld = 11, 57, 57, 384                       # 35 739 pixels: not a multiple of 128
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(B * H * W, ld, generator=g)
+    x[:, cin:] = float("nan")
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    d = ConvDesc(B, H, W, cin, ld, cout, cout, 1, 1, 1, 1, 0, 0)
+    xg, wg, scg, shg = x.to(dev), w.to(dev).view(1, cout, cin).contiguous(), sc.to(dev), sh.to(dev)
+    for bn in (True, False):
+        a = (torch.relu(x[:, :cin] * sc + sh) if bn else x[:, :cin]).double()
+        want = a @ w.double().t()
+        for stats in (True, False):
+            y = torch.full((B * H * W, cout), float("nan"), device=dev)
+            ssum = torch.zeros(cout, dtype=torch.float64, device=dev)
+            ssq = torch.zeros_like(ssum)
+            check(L.rdm_conv2d_fwd(C.byref(d), ptr(xg), ptr(wg), None, ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(y),
+                                   ptr(ssum) if stats else None, ptr(ssq) if stats else None, stream()))
+            assert rel(y.cpu().double(), want) < TOL
+            if stats:
+                assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+
+
 def test_conv_linearity_full_size():
     """Size-independent property at the bench geometry (B=16, 57x76, 96->2736): conv(a*x1+b*x2) == a*conv(x1)+b*conv(x2)."""
     from md_rdm_amd import _lib
