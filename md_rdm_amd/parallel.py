@@ -21,9 +21,10 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, flat_grad, slices, extra=(), group=None, buffers=()):
+    def __init__(self, flat_grad, slices, extra=(), group=None, buffers=(), flat_buffers=None):
         self.flat, self.slices, self.extra, self.group = flat_grad, list(slices), list(extra), group
         self.buffers = [b for b in buffers if b.numel()]
+        self.flat_buffers = list(flat_buffers) if flat_buffers else None     # contiguous storage behind `buffers` (one tensor per dtype)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles = []
 
@@ -39,6 +40,10 @@ class GradSync:
     def sync_buffers(self):
         """torch DDP's ``broadcast_buffers``: every rank takes rank 0's BatchNorm running statistics / counters."""
         if self.world == 1 or not self.buffers:
+            return
+        if self.flat_buffers is not None:                            # the model keeps its buffers in flat storage: broadcast in place
+            for buf in self.flat_buffers:
+                dist.broadcast(buf, 0, group=self.group)
             return
         floats = [b for b in self.buffers if b.dtype == torch.float32]
         if floats:                                                   # one coalesced broadcast instead of ~480 tiny ones
@@ -81,14 +86,13 @@ def attach(model, group=None, broadcast_buffers=True):
     flat, gflat = model._flat[0], model._flat[1]
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, 0, group=group)                 # identical replicas
-        for b in model.buffers():
-            if b.numel():
-                dist.broadcast(b, 0, group=group)
+        for b in (getattr(model, "_flat_buffers", None) or [b for b in model.buffers() if b.numel()]):
+            dist.broadcast(b, 0, group=group)
         for p in model.weight_layer.parameters():
             if p.numel():
                 dist.broadcast(p.data, 0, group=group)
     sync = GradSync(gflat, model.stage_slices(), extra=[p for p in model.weight_layer.parameters() if p.requires_grad], group=group,
-                    buffers=list(model.buffers()))
+                    buffers=list(model.buffers()), flat_buffers=getattr(model, "_flat_buffers", None))
     model.direct_grads = True
     model.grad_ready_hook = sync.on_stage
     if broadcast_buffers and sync.world > 1:

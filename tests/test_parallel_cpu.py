@@ -31,6 +31,12 @@ def _worker(rank, world, port, q):
     sb = GradSync(flat, slices, buffers=[rm, nbt, torch.zeros(0)])
     sb.sync_buffers()
     ok = ok and torch.equal(rm, torch.full((7,), 3.0)) and int(nbt) == 5 and nbt.dtype == torch.int64
+    # the same with the buffers kept as views of flat storage (DepthEstimationNet._flatten_buffers): broadcast in place, no copies
+    fbuf, ibuf = torch.full((12,), float(rank + 1)), torch.full((3,), rank + 7, dtype=torch.int64)
+    views = [fbuf[0:5], fbuf[5:12].view(7), ibuf[0:1].view(()), ibuf[1:3]]
+    sf = GradSync(flat, slices, buffers=views, flat_buffers=[fbuf, ibuf])
+    sf.sync_buffers()
+    ok = ok and all(torch.equal(v, torch.full_like(v, 1.0 if v.dtype == torch.float32 else 7)) for v in views)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
