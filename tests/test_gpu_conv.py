@@ -125,6 +125,11 @@ def test_conv1x1_big_grid(cin, cout):
             assert rel(y.cpu().double(), want) < TOL
             if stats:
                 assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+        # weight gradient of the same operator (long contraction over the 35 739 pixels; ragged pixel tail, ragged channel tiles)
+        gy = torch.randn(B * H * W, cout, generator=g)
+        dw = torch.zeros(1, cout, cin, device=dev)
+        check(L.rdm_conv2d_wgrad(C.byref(d), ptr(gy.to(dev)), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), stream()))
+        assert rel(dw[0].cpu().double(), gy.double().t() @ a) < TOL
 
 
 def test_conv_linearity_full_size():
