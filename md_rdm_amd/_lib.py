@@ -32,6 +32,7 @@ _SIGNATURES = {
     "rdm_nyu_preprocess": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "rdm_microbench_copy": (C.c_int, [vp, vp, i64, vp]),
     "rdm_microbench_mfma_f32": (C.c_int, [vp, i32, i32, vp]),
+    "rdm_microbench_mfma_staged_f32": (C.c_int, [vp, i64, i32, i32, i32, i64, vp]),
     "rdm_microbench_gemm_dma_f32": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),

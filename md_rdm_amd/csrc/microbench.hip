@@ -312,6 +312,77 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma32_f32(const float* A, int l
   }
 }
 
+// EXPERIMENT 1d: k_gemm_dma32_f32 on PRE-TILED operands - A as [m-tile][k-slab][128 rows][32 floats], W as [n-tile][k-slab][96][32], each
+// (tile, slab) image contiguous (16 / 12 KB) and already chunk-swizzled - so every DMA wave-instruction copies 1 KiB of CONSECUTIVE bytes
+// instead of 8 row pieces 128 bytes long and a row stride apart.  Same LDS image, same fragment reads, same MFMA loop: what is the
+// access SHAPE of the staging loads worth?
+template <int NBUF>
+__global__ __launch_bounds__(256, 2) void k_gemm_dma32_tiled_f32(const float* At, const float* Wt, float* Cc, int ldc, int M, int N, int K, int grp) {
+  constexpr int MT = 4, NT = 3, BM = 128, BN = 96, BK = 32, NA = 4, NB = 3;
+  __shared__ __attribute__((aligned(1024))) float smem[NBUF * (BM + BN) * BK];
+  float* const sm = smem;
+  auto As = [&](int buf) { return sm + buf * (BM + BN) * BK; };
+  auto Bs = [&](int buf) { return sm + buf * (BM + BN) * BK + BM * BK; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wrow = (wave >> 1) * MT * 16, wcol = (wave & 1) * NT * 16;
+  int bx, by;
+  tile_order(grp, bx, by);
+  const int n0 = bx * BN, m0 = by * BM;
+  const int nk = K / BK;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(At), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned abase = (unsigned)by * (unsigned)nk * (BM * BK * 4u), wbase = (unsigned)bx * (unsigned)nk * (BN * BK * 4u);
+  auto issue = [&](int buf, int s) {
+#pragma unroll
+    for (int t = 0; t < NA; ++t) lds_dma16_buf(ra, (unsigned)((wave + 4 * t) * 1024 + lane * 16), abase + (unsigned)s * (BM * BK * 4u), As(buf) + (wave + 4 * t) * 256);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) lds_dma16_buf(rw, (unsigned)((wave + 4 * t) * 1024 + lane * 16), wbase + (unsigned)s * (BN * BK * 4u), Bs(buf) + (wave + 4 * t) * 256);
+  };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b)
+    if (b < nk) issue(b, b);
+  const int sl0 = ((g ^ (l16 >> 1)) & 7) * 4, sl1 = (((g + 4) ^ (l16 >> 1)) & 7) * 4;
+  for (int s = 0; s < nk; ++s) {
+    if (NBUF == 2 || s + NBUF - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NA + NB) * (NBUF - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NBUF - 1 < nk) issue((s + NBUF - 1) % NBUF, s + NBUF - 1);
+    const int buf = s % NBUF;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 a4[MT], b4[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const f32x4*>(As(buf) + (wrow + i * 16 + l16) * BK + (h ? sl1 : sl0));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Bs(buf) + (wcol + j * 16 + l16) * BK + (h ? sl1 : sl0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], b4[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wcol + j * 16 + l16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wrow + i * 16 + g * 4 + r;
+        if (n < N && m < M) Cc[(long)m * ldc + n] = acc[i][j][r];
+      }
+  }
+}
+
 // EXPERIMENT 2: no LDS and no workgroup barrier at all - every wave loads its own MFMA fragments straight from global memory
 // (lane (row, kq) <- 16 bytes A[row][4kq .. 4kq+3], the same k permutation) NS slabs ahead into registers.  The A rows are loaded by
 // the WN waves that share them and the W rows by the WM waves (through L1 / L2); what it buys is waves that never wait for each other.
@@ -378,7 +449,8 @@ int launch_gemm_dma(const float* a, int lda, const float* w, int ldw, float* c, 
   const int grp = variant / 100;                    // variant = 100 * row-group size + kernel id
   variant %= 100;
   dim3 grid(cdiv(n, 96), cdiv(m, 128));
-  if (variant == 30) hipLaunchKernelGGL(k_gemm_dma_big_f32<2>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
+  if (variant == 40) hipLaunchKernelGGL(k_gemm_dma32_tiled_f32<2>, grid, dim3(256), 0, stream, a, w, c, ldc, m, n, k, grp);     // a, w: PRE-TILED images (lda / ldw unused)
+  else if (variant == 30) hipLaunchKernelGGL(k_gemm_dma_big_f32<2>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 31) hipLaunchKernelGGL(k_gemm_dma_big_f32<3>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 20) hipLaunchKernelGGL((k_gemm_dma32_f32<4, 3, 2, 2, 2>), grid, dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 21) hipLaunchKernelGGL((k_gemm_dma32_f32<2, 3, 2, 2, 3>), dim3(cdiv(n, 96), cdiv(m, 64)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
@@ -396,7 +468,7 @@ int launch_gemm_dma(const float* a, int lda, const float* w, int ldw, float* c, 
 // per slab.  3: + the slab's LDS-DMA staging (4 x global_load_lds_dwordx4 per wave from an L2-resident 64 KB source) with the 2-buffer
 // wait/barrier of k_gemm_dma_f32.  Each step adds exactly one ingredient of the real kernels to the 48-MFMA slab.
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void k_mfma_loop_tile(float* out, int iters, float seed, const float* src) {
+__global__ __launch_bounds__(256, 4) void k_mfma_loop_tile(float* out, int iters, float seed, const float* src, unsigned span_mask) {
   __shared__ __attribute__((aligned(1024))) float smem[2 * (128 + 96) * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
   for (int i = threadIdx.x; i < 2 * (128 + 96) * 16; i += 256) smem[i] = seed + i * 1e-6f;
@@ -423,12 +495,15 @@ __global__ __launch_bounds__(256, 4) void k_mfma_loop_tile(float* out, int iters
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         float* nb6 = smem + (buf ^ 1) * (128 + 96) * 16;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 1 << 20, 0x00020000);
-        const unsigned vo = (unsigned)(((blockIdx.x & 3) * 4096 + wave * 1024 + lane * 4) * 4);
+        // source: a window of (span_mask + 1) floats walked in 16 KB steps, a different phase per workgroup - span 64 KB: L1-resident,
+        // a few MB: L2-resident, hundreds of MB: Infinity Cache / HBM (every step reads 14 KB like a real 128 x 96 x 16 slab)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned vo = (unsigned)((wave * 1024 + lane * 4) * 4);
+        const unsigned so = (((unsigned)blockIdx.x * 40503u + (unsigned)it) * 4096u & span_mask) * 4u;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) lds_dma16_buf(rs, vo, (unsigned)((t * 256 + (it & 7) * 512) * 4), nb6 + (wave + 4 * t) * 256);
-        lds_dma16_buf(rs, vo, 128 * 4, nb6 + 128 * 16 + wave * 256);
-        if (wave < 2) lds_dma16_buf(rs, vo, 64 * 4, nb6 + 128 * 16 + (4 + wave) * 256);
+        for (int t = 0; t < 2; ++t) lds_dma16_buf(rs, vo, so + (unsigned)(t * 256 * 4), nb6 + (wave + 4 * t) * 256);
+        lds_dma16_buf(rs, vo, so + 128 * 4, nb6 + 128 * 16 + wave * 256);
+        if (wave < 2) lds_dma16_buf(rs, vo, so + 64 * 4, nb6 + 128 * 16 + (4 + wave) * 256);
       } else {
       if (MODE != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // 5: never wait for the DMA (timing only: what is ISSUING it worth?)
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -467,16 +542,16 @@ __global__ __launch_bounds__(256, 4) void k_mfma_loop_tile(float* out, int iters
   if (sacc == 123.456f) out[blockIdx.x] = sacc;
 }
 
-int launch_mfma_tile(float* scratch, int blocks, int iters, hipStream_t stream) {
-  const int mode = iters & 7;                       // low three bits of the iteration count select the ingredient set
-  const float* src = scratch + 4096;                // >= 64 KB of the scratch buffer serve as the DMA source
-  if (mode == 0) hipLaunchKernelGGL(k_mfma_loop_tile<0>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else if (mode == 1) hipLaunchKernelGGL(k_mfma_loop_tile<1>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else if (mode == 2) hipLaunchKernelGGL(k_mfma_loop_tile<2>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else if (mode == 3) hipLaunchKernelGGL(k_mfma_loop_tile<3>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else if (mode == 4) hipLaunchKernelGGL(k_mfma_loop_tile<4>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else if (mode == 5) hipLaunchKernelGGL(k_mfma_loop_tile<5>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
-  else hipLaunchKernelGGL(k_mfma_loop_tile<6>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src);
+int launch_mfma_tile(float* scratch, int blocks, int iters, hipStream_t stream, int mode_in = -1, unsigned span_mask = 16383u) {
+  const int mode = mode_in >= 0 ? mode_in : (iters & 7);       // (legacy: low three bits of the iteration count select the ingredient set)
+  const float* src = scratch + 4096;                // the scratch buffer behind the first 16 KB is the DMA source
+  if (mode == 0) hipLaunchKernelGGL(k_mfma_loop_tile<0>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else if (mode == 1) hipLaunchKernelGGL(k_mfma_loop_tile<1>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else if (mode == 2) hipLaunchKernelGGL(k_mfma_loop_tile<2>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else if (mode == 3) hipLaunchKernelGGL(k_mfma_loop_tile<3>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else if (mode == 4) hipLaunchKernelGGL(k_mfma_loop_tile<4>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else if (mode == 5) hipLaunchKernelGGL(k_mfma_loop_tile<5>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
+  else hipLaunchKernelGGL(k_mfma_loop_tile<6>, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f, src, span_mask);
   RDM_LAUNCH_OK();
   return RDM_OK;
 }
@@ -501,6 +576,16 @@ int rdm_microbench_mfma_f32(float* scratch, int32_t blocks, int32_t iters, rdm_s
   hipLaunchKernelGGL(k_mfma_loop, dim3(blocks), dim3(256), 0, stream, scratch, iters, 1.0f);
   RDM_LAUNCH_OK();
   return RDM_OK;
+}
+
+/* the tile-pattern MFMA loop with one staging ingredient (mode 0..6, k_mfma_loop_tile); mode 6 reads its DMA source from a window of
+ * span_floats (a power of two, <= scratch_floats - 8192) of the scratch buffer: where the data comes from (L1 / L2 / Infinity Cache / HBM) */
+int rdm_microbench_mfma_staged_f32(float* scratch, int64_t scratch_floats, int32_t blocks, int32_t slabs, int32_t mode, int64_t span_floats,
+                                   rdm_stream_t stream) {
+  RDM_CHECK_ARG(scratch && blocks > 0 && slabs > 0 && mode >= 0 && mode <= 6, "microbench_mfma_staged: bad argument");
+  RDM_CHECK_ARG(span_floats >= 16384 && (span_floats & (span_floats - 1)) == 0 && span_floats + 8192 <= scratch_floats && span_floats <= (1LL << 29),
+                "microbench_mfma_staged: span must be a power of two of floats inside the scratch buffer");
+  return launch_mfma_tile(scratch, blocks, slabs, stream, mode, (unsigned)(span_floats - 1));
 }
 
 /* EXPERIMENT: LDS-DMA staged f32 GEMM C[M][N] = A[M][K] * W[N][K]^T (K multiple of 16); variant = LDS buffers (2 or 3) */
