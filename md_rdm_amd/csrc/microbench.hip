@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma32_f32(const float* A, int l
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wrow + i * 16 + g * 4 + r;
-        if (n < N && m < M) Cc[(long)m * ldc + n] = acc[i][j][r];
+        if (n < N && m < M && (ldc > 0 || acc[i][j][r] == 123.456f)) Cc[(long)m * (ldc > 0 ? ldc : -ldc) + n] = acc[i][j][r];   // ldc < 0: timing probe without the output stores
       }
   }
 }
@@ -449,7 +449,8 @@ int launch_gemm_dma(const float* a, int lda, const float* w, int ldw, float* c, 
   const int grp = variant / 100;                    // variant = 100 * row-group size + kernel id
   variant %= 100;
   dim3 grid(cdiv(n, 96), cdiv(m, 128));
-  if (variant == 40) hipLaunchKernelGGL(k_gemm_dma32_tiled_f32<2>, grid, dim3(256), 0, stream, a, w, c, ldc, m, n, k, grp);     // a, w: PRE-TILED images (lda / ldw unused)
+  if (variant == 50) hipLaunchKernelGGL((k_gemm_dma32_f32<4, 3, 2, 2, 2>), grid, dim3(256), 0, stream, a, lda, w, ldw, c, -ldc, m, n, k, grp);   // no output stores
+  else if (variant == 40) hipLaunchKernelGGL(k_gemm_dma32_tiled_f32<2>, grid, dim3(256), 0, stream, a, w, c, ldc, m, n, k, grp);     // a, w: PRE-TILED images (lda / ldw unused)
   else if (variant == 30) hipLaunchKernelGGL(k_gemm_dma_big_f32<2>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 31) hipLaunchKernelGGL(k_gemm_dma_big_f32<3>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 20) hipLaunchKernelGGL((k_gemm_dma32_f32<4, 3, 2, 2, 2>), grid, dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
