@@ -325,6 +325,104 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1x1 forward with a 256 x 128 macro tile and LDS-DMA staging (big grids: dense_e2 / dense_e3 bottlenecks).
+// Round-2 measurements (csrc/microbench.hip): on these shapes the vendor GEMM reaches 130 TFLOP/s where the
+// 128 x 48 / 128 x 96 register-staged tiles reach 98 - 114 - the small tiles pay the tile boundary (prologue latency, epilogue, drain)
+// thousands of times.  Here a workgroup owns 256 pixels x 128 channels (wave tile 128 x 64: 128 accumulator registers), both operands
+// reach LDS by `buffer_load_dwordx4 ... lds` (SRD + one 32-bit lane offset per 1-KiB piece, the slab advance in a scalar offset: no
+// staging registers, no ds_write, no vector address arithmetic), 3 buffers of 24 KB keep one slab in flight across each barrier,
+// 2 workgroups per CU.  LDS image: lane-linear [row][16 floats]; the 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3)
+// (applied to the SOURCE address), so a fragment ds_read_b128 (16 rows x one chunk) touches 16 distinct slots of the 256-byte bank
+// row.  Lane (row, kq) takes channels 4kq .. 4kq+3 of the slab and feeds element e to MFMA step e - a permutation of k shared by
+// both operands.  The consumer BN-ReLU is applied to the A fragments (8 VALU per 16-row tile and slab next to 16 MFMAs).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass cannot type-check the gfx950 builtin and would silently drop the kernel's stub)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+
+template <int EPI, bool BNRELU>
+__global__ __launch_bounds__(256, 2) void conv1x1_dma256_kernel(FwdArgs p) {
+  constexpr int MT = 8, NT = 4, BM = 256, BN = 128, NBUF = 3, NA = BM / 16 / 4, NB = BN / 16 / 4;      // 1-KiB pieces (16 rows x 64 B) per wave and slab: 4 + 2
+  constexpr int SLAB = (BM + BN) * BK + (BNRELU ? 512 : 0);                         // + one piece each for the slab's 16 scale / 16 shift values
+  __shared__ __attribute__((aligned(1024))) float smem[NBUF * SLAB];               // ONE object (a second one makes hipcc drain vmcnt before every ds_read)
+  float* const sm = smem;
+  auto As = [&](int buf) { return sm + buf * SLAB; };
+  auto Bs = [&](int buf) { return sm + buf * SLAB + BM * BK; };
+  auto Cf = [&](int buf) { return sm + buf * SLAB + (BM + BN) * BK; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wrow = (wave >> 1) * MT * 16, wcol = (wave & 1) * NT * 16;
+  int bx, by, bz;
+  xcd_block_order(p.xcd_flat, bx, by, bz);
+  const int n0 = bx * BN, m0 = by * BM;
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.A, p.a_bytes), rw = make_srd(p.Wt, p.w_bytes);
+  // the consumer BN-ReLU's coefficients travel with the slab: wave 0 copies the 16 scale values, wave 1 the 16 shift values (lanes 0..3,
+  // the other lanes are out of range and write zeros) - every load of the loop is an LDS-DMA, so the counted waits stay exact
+  const __amdgpu_buffer_rsrc_t rc = make_srd(wave == 0 ? p.a_scale : p.a_shift, (unsigned)(p.C * 4));
+  const unsigned coff = lane < 4 ? (unsigned)(lane * 16) : OOB;
+  const int prow = lane >> 2, pch = (lane & 3) ^ ((prow >> 2) & 3);
+  unsigned aoff[NA], boff[NB];
+#pragma unroll
+  for (int t = 0; t < NA; ++t) aoff[t] = (unsigned)(min(m0 + (wave + 4 * t) * 16 + prow, p.M - 1) * p.lda + pch * 4) * 4u;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) boff[t] = (unsigned)(min(n0 + (wave + 4 * t) * 16 + prow, p.N - 1) * p.ldw + pch * 4) * 4u;
+  auto issue = [&](int buf, int s) {
+    const unsigned so = (unsigned)s * (BK * 4u);
+#pragma unroll
+    for (int t = 0; t < NA; ++t) lds_dma16(ra, aoff[t], so, As(buf) + (wave + 4 * t) * 256);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) lds_dma16(rw, boff[t], so, Bs(buf) + (wave + 4 * t) * 256);
+    if (BNRELU && wave < 2) lds_dma16(rc, coff, so, Cf(buf) + wave * 256);
+  };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.C / BK;
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b)
+    if (b < nk) issue(b, b);
+  const int sl = ((g ^ (l16 >> 2)) & 3) * 4;
+  for (int s = 0; s < nk; ++s) {
+    // slab s has landed: all but the youngest (NBUF - 2) groups of this wave's DMAs (the tail has nothing younger in flight)
+    if (s + NBUF - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (BNRELU && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NA + NB + 1) * (NBUF - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NA + NB) * (NBUF - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NBUF - 1 < nk) issue((s + NBUF - 1) % NBUF, s + NBUF - 1);      // into the buffer slab s-1 was read from: every wave is past it
+    const int buf = s % NBUF;
+    f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (BNRELU) { sc = *reinterpret_cast<const f32x4*>(Cf(buf) + g * 4); sh = *reinterpret_cast<const f32x4*>(Cf(buf) + 256 + g * 4); }
+    f32x4 b4[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Bs(buf) + (wcol + j * 16 + l16) * BK + sl);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                        // the A fragments in two halves: 16 + 16 fragment registers beside 128 accumulators
+      f32x4 a4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = *reinterpret_cast<const f32x4*>(As(buf) + (wrow + (h * 4 + i) * 16 + l16) * BK + sl);
+        if (BNRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[i][e] = fmaxf(fmaf(a4[i][e], sc[e], sh[e]), 0.f);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], b4[j][e], acc[h * 4 + i][j], 0, 0, 0);
+    }
+  }
+  conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, wcol, l16, g);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 forward with an LDS HALO tile (the live DenseNet 3x3: 48 outputs, K = 9*Cb).
 // A workgroup owns 256 consecutive output pixels (linear NHWC index) x 48 channels.  Per 16-channel
 // slab it stages ONE halo run of 256 + 2*(W+1) pixels - BN scale/shift + ReLU applied once per
@@ -1076,6 +1174,19 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     }
 #undef RDM_HALO
 #undef RDM_HALO2
+    RDM_LAUNCH_OK();
+    return 0;
+  }
+  // mid-size 1x1 forward (dense_e3: 17 632 pixels x 1392 channels): 256 x 128 macro tile on the LDS-DMA pipeline (conv1x1_dma256_kernel).
+  // In-process A/B with the BN-ReLU prologue and the statistics epilogue (tools/conv_microbench.py): K = 384 / 576 / 720 / 912
+  // 100.4 / 108.0 / 112.5 / 115.0 vs 95.2 / 101.4 / 104.3 / 105.8 TFLOP/s (+5.5 .. 8.7 %); at dense_e2 size (69 312 pixels, K <= 336)
+  // the two are level (109.5 vs 110.6 at K = 336), so the 128 x 96 register-staged kernel stays there.
+  if (!taps && !b_kstrided && split == 1 && (epi == EPI_STORE || epi == EPI_STORE_STATS) && !a.add_out && a.bias == nullptr && a.M >= 16384 && a.M < 32768 &&
+      a.N >= 512 && g_variant != 38) {
+    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 256), 1);
+    const bool bn = a.a_scale != nullptr;
+    if (epi == EPI_STORE) { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, false>), grid, dim3(256), 0, s, a); }
+    else { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, false>), grid, dim3(256), 0, s, a); }
     RDM_LAUNCH_OK();
     return 0;
   }

@@ -154,16 +154,16 @@ __global__ __launch_bounds__(256, 4) void k_gemm_dma_f32(const float* A, int lda
 // per slab, 112 with four LDS-DMA instructions per wave and slab on top - waited for or not - 124 with two), so this variant stages half
 // as many bytes per MFMA: wave tile 128 x 96 (MT = 8, NT = 6: 192 accumulator registers, 2 waves per SIMD), workgroup tile 256 x 192,
 // 7 DMA instructions per wave and slab next to 192 MFMAs instead of 3.5 next to 48.
-template <int NBUF>
-__global__ __launch_bounds__(256, 2) void k_gemm_dma_big_f32(const float* A, int lda, const float* Wt, int ldw, float* Cc, int ldc, int M, int N, int K, int grp) {
-  constexpr int MT = 8, NT = 6, BM = 256, BN = 192, BK = 16, NA = 4, NB = 3;
+template <int NBUF, int NT, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_gemm_dma_big_f32(const float* A, int lda, const float* Wt, int ldw, float* Cc, int ldc, int M, int N, int K, int grp) {
+  constexpr int MT = 8, BM = 256, BN = NT * 32, BK = 16, NA = 4, NB = BN / 64;
   __shared__ __attribute__((aligned(1024))) float smem[NBUF * (BM + BN) * BK];
   float* const sm = smem;
   auto As = [&](int buf) { return sm + buf * (BM + BN) * BK; };
   auto Bs = [&](int buf) { return sm + buf * (BM + BN) * BK + BM * BK; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const int wrow = (wave >> 1) * 128, wcol = (wave & 1) * 96;
+  const int wrow = (wave >> 1) * 128, wcol = (wave & 1) * (NT * 16);
   int bx, by;
   tile_order(grp, bx, by);
   const int n0 = bx * BN, m0 = by * BM;
@@ -451,8 +451,11 @@ int launch_gemm_dma(const float* a, int lda, const float* w, int ldw, float* c, 
   dim3 grid(cdiv(n, 96), cdiv(m, 128));
   if (variant == 50) hipLaunchKernelGGL((k_gemm_dma32_f32<4, 3, 2, 2, 2>), grid, dim3(256), 0, stream, a, lda, w, ldw, c, -ldc, m, n, k, grp);   // no output stores
   else if (variant == 40) hipLaunchKernelGGL(k_gemm_dma32_tiled_f32<2>, grid, dim3(256), 0, stream, a, w, c, ldc, m, n, k, grp);     // a, w: PRE-TILED images (lda / ldw unused)
-  else if (variant == 30) hipLaunchKernelGGL(k_gemm_dma_big_f32<2>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
-  else if (variant == 31) hipLaunchKernelGGL(k_gemm_dma_big_f32<3>, dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
+  else if (variant == 30) hipLaunchKernelGGL((k_gemm_dma_big_f32<2, 6, 2>), dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
+  else if (variant == 31) hipLaunchKernelGGL((k_gemm_dma_big_f32<3, 6, 2>), dim3(cdiv(n, 192), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
+  else if (variant == 32) hipLaunchKernelGGL((k_gemm_dma_big_f32<4, 4, 1>), dim3(cdiv(n, 128), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);   // 256 x 128, 4 buffers, ONE workgroup per CU
+  else if (variant == 33) hipLaunchKernelGGL((k_gemm_dma_big_f32<3, 4, 2>), dim3(cdiv(n, 128), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);   // 256 x 128, 3 buffers, two per CU
+  else if (variant == 34) hipLaunchKernelGGL((k_gemm_dma_big_f32<6, 4, 1>), dim3(cdiv(n, 128), cdiv(m, 256)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);   // 6 buffers, one per CU
   else if (variant == 20) hipLaunchKernelGGL((k_gemm_dma32_f32<4, 3, 2, 2, 2>), grid, dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 21) hipLaunchKernelGGL((k_gemm_dma32_f32<2, 3, 2, 2, 3>), dim3(cdiv(n, 96), cdiv(m, 64)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);
   else if (variant == 22) hipLaunchKernelGGL((k_gemm_dma32_f32<2, 3, 2, 2, 2>), dim3(cdiv(n, 96), cdiv(m, 64)), dim3(256), 0, stream, a, lda, w, ldw, c, ldc, m, n, k, grp);

@@ -95,7 +95,7 @@ def test_conv_family(case):
             assert rel(s1.cpu(), (refm.double() * xin.double()).sum((0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout", [(96, 2736), (144, 200), (336, 208), (48, 96)])
+@pytest.mark.parametrize("cin,cout", [(96, 2736), (144, 1392), (144, 200), (336, 208), (48, 96), (16, 520)])
 def test_conv1x1_big_grid(cin, cout):
     """The big-grid 1x1 forward (>= 32 768 pixels, dense_e2's regime) vs an f64 matmul: K a multiple of 32 and with a 16-channel tail,
     ragged M and N tiles, the BN-ReLU prologue, the statistics epilogue - and NaN in the channels BEHIND the contracted prefix of the

@@ -15,7 +15,7 @@ def bench(fn, reps=5):
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t) / reps)
     return best
-for (B, H, W, N, K) in ((16, 57, 76, 2736, 320), (16, 57, 76, 2736, 96), (16, 57, 76, 2736, 1024), (16, 29, 38, 1392, 704)):
+for (B, H, W, N, K) in ((16, 29, 38, 1392, 704), (16, 29, 38, 1392, 384), (16, 57, 76, 2736, 320), (16, 15, 19, 720, 1536)):
     M = B * H * W
     A = torch.randn(M, K, device=dev); Wt = torch.randn(N, K, device=dev) * 0.05
     Cn = torch.empty(M, N, device=dev); Cr = torch.empty(M, N, device=dev)
@@ -34,7 +34,7 @@ for (B, H, W, N, K) in ((16, 57, 76, 2736, 320), (16, 57, 76, 2736, 96), (16, 57
         src = (torch.arange(8, device=dev)[None, :] ^ ((r[:, None] >> 1) & 7))                                    # slot c of row r <- logical chunk c ^ ((r >> 1) & 7)
         return torch.gather(P, 3, src[None, None, :, :, None].expand(P.shape[0], P.shape[1], rows_per_tile, 8, 4).contiguous()).contiguous()
     At, Wtt = (tiled(A, 128), tiled(Wt, 96)) if K % 32 == 0 else (None, None)
-    for v in (20, 50, 40):
+    for v in (20, 32, 33, 34):
         if v == 40 and At is None: continue
         if v == 40:
             new = lambda: check(L.rdm_microbench_gemm_dma_f32(ptr(At), K, ptr(Wtt), K, ptr(Cn), N, M, N, K, v, stream()))
