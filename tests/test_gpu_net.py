@@ -118,7 +118,13 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
     flips (tests/test_oracle_net.py::test_f32_gradient_noise_floor).  Measured on MI355X: every tensor sits at a relative L2
     error of 0.6-1.5 % in BOTH float32 evaluations (medians 7.8e-3 HIP / 7.3e-3 oracle, ratio median 0.99, p90 1.14) - except
     the handful the float32 oracle happens to evaluate without a flip (d_1 denselayer24: 2e-5), where its own error says nothing
-    about the noise level; the floors are 2x the typical L2 level and 4x the p90 norm error."""
+    about the noise level; the floors are 2x the typical L2 level and 4x the p90 norm error.
+    (b) cannot be tighter than geometry allows: | ||g'|| - ||g|| | / ||g|| = e cos(theta) + O(e^2) for an error of relative length e at
+    angle theta to the gradient, and an error that is NOT systematically aligned with the gradient has |cos(theta)| ~ 1 / sqrt(numel) -
+    a 288-element BatchNorm bias with e = 1.2 % lands at 2e-3 once in a while (seen: 2.3e-3, a run-to-run effect of the atomics'
+    summation order picking different ReLU flips).  So a tensor may also pass (b) with  e x 4 / sqrt(numel) + e^2  (4 sigma of a random
+    direction): 2.9e-3 for that bias, 5e-5 - i.e. irrelevant next to the floor - for a 1 M-element weight, where only a SYSTEMATIC
+    error (wrong scale, missing term) could move the norm."""
     from md_rdm_amd import harness
     K_L2, FLOOR_L2, K_NORM, FLOOR_NORM = 2.0, 1.5e-2, 3.0, 1.5e-3
     B = 2
@@ -149,7 +155,7 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
         import json
         with open(os.environ["RDM_GRAD_REPORT"], "w") as fh:
             json.dump(report, fh)
-    bad = [t for t in report if t[1] > K_L2 * t[2] + FLOOR_L2 or t[3] > K_NORM * t[4] + FLOOR_NORM]
+    bad = [t for t in report if t[1] > K_L2 * t[2] + FLOOR_L2 or t[3] > max(K_NORM * t[4] + FLOOR_NORM, t[1] * 4.0 / t[5] ** 0.5 + t[1] ** 2)]
     assert not bad, "per-tensor gradient parity failed for %d tensors (name, l2 hip, l2 f32, norm hip, norm f32, numel): %r" % (
         len(bad), sorted(bad, key=lambda t: -t[1])[:5])
 
