@@ -64,6 +64,16 @@ void rdm_debug_variant(int32_t v);
  * a K-split launcher that also enqueues its zero-fill or reduction counts once per enqueued kernel family) */
 int64_t rdm_launch_count(void);
 
+/* Launch census (test instrumentation): while enabled, every MFMA conv launcher records which kernel VARIANT it picked - e.g.
+ * "conv3x3_halo_kernel/dgrad/px256/hl6/MASK_STATS", "conv_wgrad3_row_kernel/48x256x3/splitK", "conv1x1_dma256_kernel/STORE_STATS/bn1" -
+ * so tests/test_gpu_conv.py can assert that the variants the headline geometry (B=16, 228x304) selects are the ones its parity cases
+ * ran.  rdm_census_count() snapshots the table and returns its size; rdm_census_entry(i) reads entry i of that snapshot (the name
+ * stays valid until the next rdm_census_count()). */
+void rdm_census_enable(int32_t on);
+void rdm_census_reset(void);
+int32_t rdm_census_count(void);
+int rdm_census_entry(int32_t i, const char** name, int64_t* launches);
+
 /* Attainable-peak microbenchmarks: float4 stream copy (HBM) and a register-only
  * v_mfma_f32_16x16x4_f32 loop (blocks x 4 waves x iters x 12 MFMAs of 2048 FLOP). */
 int rdm_microbench_copy(const float* src, float* dst, int64_t n_floats, rdm_stream_t stream);
@@ -109,6 +119,18 @@ int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w_pac
 /* dw[r*kw+s][n][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * f(x[b, oy*sh-ph+r, ox*sw-pw+s, c]);  dw pre-zeroed. */
 int rdm_conv2d_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale,
                      const float* bn_shift, float* dw_packed, rdm_stream_t stream);
+
+/* The same three operators with the K-split chosen by the caller: split_k = 0 keeps the launcher's own choice (what the plain entry
+ * points do), 1 forbids splitting (no atomics: one workgroup owns every output element, bit-reproducible), n > 1 asks for n partial
+ * sums added with f32 atomics into a zeroed output (the launcher clamps n to the number of K slabs; statistics / bias epilogues
+ * that are not linear in the partials always run unsplit). */
+int rdm_conv2d_fwd_ex(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bias, const float* bn_scale,
+                      const float* bn_shift, float* y, double* stat_sum, double* stat_sq, int32_t split_k, rdm_stream_t stream);
+int rdm_conv2d_dgrad_ex(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
+                        int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, int32_t split_k,
+                        rdm_stream_t stream);
+int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
+                        float* dw_packed, int32_t split_k, rdm_stream_t stream);
 
 /* [out][in][kh][kw] (PyTorch) <-> [tap][out_pad][in] (packed); rows >= out_c are zero-filled. */
 int rdm_pack_conv_weight(const float* w_oihw, float* w_packed, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,

@@ -25,6 +25,10 @@ _SIGNATURES = {
     "rdm_profile_enable": (None, [i32]),
     "rdm_debug_variant": (None, [i32]),
     "rdm_launch_count": (i64, []),
+    "rdm_census_enable": (None, [i32]),
+    "rdm_census_reset": (None, []),
+    "rdm_census_count": (i32, []),
+    "rdm_census_entry": (C.c_int, [i32, C.POINTER(C.c_char_p), C.POINTER(i64)]),
     "rdm_profile_read": (C.c_int, [C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind": (C.c_int, [i32, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]),
     "rdm_profile_kind_bytes": (f64, [i32]),
@@ -37,6 +41,9 @@ _SIGNATURES = {
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "rdm_conv2d_fwd_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "rdm_conv2d_dgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
+    "rdm_conv2d_wgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_gemm_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
@@ -117,6 +124,17 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def census():
+    """{kernel variant name: launches} recorded since the last rdm_census_reset() (rdm_census_enable(1) must be on)."""
+    L = lib()
+    out = {}
+    for i in range(L.rdm_census_count()):
+        name, n = C.c_char_p(), i64()
+        check(L.rdm_census_entry(i, C.byref(name), C.byref(n)))
+        out[name.value.decode()] = n.value
+    return out
 
 
 def exported_symbols():

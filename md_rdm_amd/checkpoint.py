@@ -7,7 +7,9 @@ A genuine Lightning 1.1.x ``.ckpt`` is a pickle that also carries non-tensor obj
 from ``save_hyperparameters``), ``callbacks`` keyed by the ``ModelCheckpoint`` CLASS, ``optimizer_states``, ``lr_schedulers``.
 torch >= 2.6 refuses those under ``weights_only=True``; only ``state_dict`` is wanted here, so the file is read with an unpickler
 that resolves every non-torch global to an inert stand-in instead of importing (or requiring) pytorch_lightning: nothing but
-tensors and containers is ever instantiated from the file.
+tensors and containers is ever instantiated from the file.  The unpickler's allow-list is a table of exact (module, name) pairs
+(tensor / storage / dtype reconstructors, plain containers, numpy's array reconstructors): `builtins.eval`, `os.system` or any other
+callable a crafted file names in a `__reduce__` resolves to the inert stand-in and has no effect (tests/test_boundary.py).
 
 Training state written by ``md_rdm_amd.train`` (``optimizer_states``, ``lr_schedulers``, ``epoch``, ``global_step``) uses the same
 top-level keys as Lightning; the optimiser entry is this stack's FusedAdamW state (flat moments), which Lightning could not
@@ -48,14 +50,70 @@ class _Inert:
     def __reduce_ex__(self, proto):
         return (_Inert, ())
 
+    def __call__(self, *a, **k):                     # a stand-in that a file tries to CALL (a function it named) returns another stand-in
+        return _Inert()
+
+    def __getattr__(self, name):
+        raise AttributeError(name)
+
+
+def _allowed_globals():
+    """EXACT (module, name) pairs the stand-in unpickler resolves to real objects: the tensor / storage / dtype reconstructors a
+    state_dict needs, plain containers, and numpy's array / scalar reconstructors.  Whole modules are never allowed - `builtins`
+    alone would hand a crafted file `eval`, `exec`, `getattr` and `__import__` through a `__reduce__`."""
+    import collections
+    allowed = {("collections", "OrderedDict"): collections.OrderedDict, ("collections", "Counter"): collections.Counter,
+               ("collections", "defaultdict"): collections.defaultdict,
+               ("builtins", "set"): set, ("builtins", "frozenset"): frozenset, ("builtins", "bytearray"): bytearray, ("builtins", "complex"): complex,
+               ("builtins", "slice"): slice, ("builtins", "range"): range, ("builtins", "dict"): dict, ("builtins", "list"): list,
+               ("builtins", "tuple"): tuple, ("builtins", "int"): int, ("builtins", "float"): float, ("builtins", "bool"): bool,
+               ("builtins", "str"): str, ("builtins", "bytes"): bytes}
+    import _codecs
+    allowed[("_codecs", "encode")] = _codecs.encode                       # how protocol-2 pickles carry bytes (numpy payloads)
+    for name in ("_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_tensor_v3", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                 "_rebuild_device_tensor_from_numpy", "_rebuild_device_tensor_from_cpu_tensor", "_rebuild_meta_tensor_no_storage"):
+        if hasattr(torch._utils, name):
+            allowed[("torch._utils", name)] = getattr(torch._utils, name)
+    allowed[("torch", "Size")] = torch.Size
+    allowed[("torch", "Tensor")] = torch.Tensor
+    allowed[("torch", "device")] = torch.device
+    allowed[("torch.nn.parameter", "Parameter")] = torch.nn.parameter.Parameter
+    allowed[("torch.serialization", "_get_layout")] = torch.serialization._get_layout
+    for name in dir(torch):
+        obj = getattr(torch, name)
+        if isinstance(obj, torch.dtype) or (name.endswith("Storage") and isinstance(obj, type)):
+            allowed[("torch", name)] = obj
+    for name in dir(torch.cuda):                                            # checkpoints saved from the GPU name torch.cuda.FloatStorage
+        if name.endswith("Storage") and isinstance(getattr(torch.cuda, name), type):
+            allowed[("torch.cuda", name)] = getattr(torch.cuda, name)
+    allowed[("torch.storage", "UntypedStorage")] = torch.storage.UntypedStorage
+    allowed[("torch.storage", "TypedStorage")] = torch.storage.TypedStorage
+    try:
+        import numpy as np
+        core = np._core if hasattr(np, "_core") else np.core
+        for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):    # numpy 1.x and 2.x spell the module differently
+            allowed[(mod, "_reconstruct")] = core.multiarray._reconstruct
+            allowed[(mod, "scalar")] = core.multiarray.scalar
+        allowed[("numpy", "ndarray")] = np.ndarray
+        allowed[("numpy", "dtype")] = np.dtype
+        for name in ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool_"):
+            allowed[("numpy", name)] = getattr(np, name)
+    except ImportError:
+        pass
+    return allowed
+
 
 class _TensorOnlyUnpickler(pickle.Unpickler):
-    _ALLOWED = ("torch", "collections", "numpy", "builtins", "_codecs")
+    """Resolves ONLY the exact globals of _allowed_globals(); every other global a file names (pytorch_lightning classes, argparse
+    Namespaces - or builtins.eval, os.system, anything a hostile file puts into a __reduce__) becomes the inert stand-in, whose
+    construction and state restoration do nothing."""
+    _ALLOWED = None
 
     def find_class(self, module, name):
-        if module.split(".")[0] in self._ALLOWED:
-            return super().find_class(module, name)
-        return _Inert
+        cls = type(self)
+        if cls._ALLOWED is None:
+            cls._ALLOWED = _allowed_globals()
+        return cls._ALLOWED.get((module, name), _Inert)
 
 
 class _TensorOnlyPickle:

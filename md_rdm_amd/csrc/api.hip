@@ -2,6 +2,10 @@
 // points declared in include/rdm_hip.h.  No torch types cross this boundary.
 #include <stdarg.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "rdm_common.h"
 #include "elementwise.h"
@@ -15,6 +19,22 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+bool g_census_on = false;
+namespace {
+std::mutex g_census_mu;
+std::map<std::string, long long> g_census;
+std::vector<std::pair<std::string, long long>> g_census_snapshot;      // stable storage for the strings rdm_census_entry hands out
+}  // namespace
+void census_hit(const char* fmt, ...) {
+  char buf[192];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lk(g_census_mu);
+  ++g_census[buf];
 }
 
 static int geom_from_desc(const rdm_conv_desc* d, ConvGeom* g) {
@@ -47,6 +67,23 @@ void rdm_debug_variant(int32_t v) {
 #endif
 }
 int64_t rdm_launch_count(void) { return rdm::g_launches; }
+void rdm_census_enable(int32_t on) { rdm::g_census_on = on != 0; }
+void rdm_census_reset(void) {
+  std::lock_guard<std::mutex> lk(g_census_mu);
+  g_census.clear();
+}
+int32_t rdm_census_count(void) {
+  std::lock_guard<std::mutex> lk(g_census_mu);
+  g_census_snapshot.assign(g_census.begin(), g_census.end());
+  return (int32_t)g_census_snapshot.size();
+}
+int rdm_census_entry(int32_t i, const char** name, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_census_mu);
+  RDM_CHECK_ARG(i >= 0 && i < (int)g_census_snapshot.size() && name && launches, "census_entry: index %d outside the last rdm_census_count()", (int)i);
+  *name = g_census_snapshot[i].first.c_str();
+  *launches = g_census_snapshot[i].second;
+  return RDM_OK;
+}
 void rdm_profile_enable(int32_t on) { profile_enable(on != 0); }
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches) {
   int n = 0;
@@ -77,6 +114,12 @@ int rdm_nyu_preprocess(const uint8_t* rgb, const float* depth, const rdm_nyu_aug
 
 int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
                    float* y, double* stat_sum, double* stat_sq, rdm_stream_t stream) {
+  return rdm_conv2d_fwd_ex(d, x, w, bias, bn_scale, bn_shift, y, stat_sum, stat_sq, 0, stream);
+}
+
+int rdm_conv2d_fwd_ex(const rdm_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
+                      float* y, double* stat_sum, double* stat_sq, int32_t split_k, rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_fwd: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
@@ -89,12 +132,19 @@ int rdm_conv2d_fwd(const rdm_conv_desc* d, const float* x, const float* w, const
   a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.out = y; a.ldc = d->out_ld; a.M = g.B * g.Ho * g.Wo; a.N = d->out_c; a.bias = bias;
   a.stat0 = stat_sum; a.stat1 = stat_sq;
+  a.split_k = split_k;
   rc = launch_conv_fwd(a, false, stat_sum ? EPI_STORE_STATS : EPI_STORE, stream);
   return rc < 0 ? rc : RDM_OK;
 }
 
 int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
                      const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, rdm_stream_t stream) {
+  return rdm_conv2d_dgrad_ex(d, dy, w, dx, dx_ld, mask_x, mask_ld, mask_scale, mask_shift, stat_a, stat_b, 0, stream);
+}
+
+int rdm_conv2d_dgrad_ex(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
+                        const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, int32_t split_k, rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_dgrad: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
@@ -109,12 +159,19 @@ int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w, fl
   a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
+  a.split_k = split_k;
   rc = launch_conv_fwd(a, true, mask_x ? EPI_MASK_STATS : EPI_STORE, stream);
   return rc < 0 ? rc : RDM_OK;
 }
 
 int rdm_conv2d_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
                      rdm_stream_t stream) {
+  return rdm_conv2d_wgrad_ex(d, dy, x, bn_scale, bn_shift, dw, 0, stream);
+}
+
+int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
+                        int32_t split_k, rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
@@ -124,6 +181,7 @@ int rdm_conv2d_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, co
   a.g = g; a.G = dy; a.ldg = d->out_ld; a.N = d->out_c;
   a.Xs = x; a.ldx = d->in_ld; a.C = d->in_c; a.x_scale = bn_scale; a.x_shift = bn_shift;
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.split_k = split_k;
   return launch_conv_wgrad(a, stream);
 }
 

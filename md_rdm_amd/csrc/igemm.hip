@@ -1043,6 +1043,11 @@ int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int
 int g_variant = 0;      // A/B switch for in-process kernel comparisons (rdm_debug_variant)
 #endif
 
+static const char* epi_name(int e) {
+  static const char* const n[5] = {"STORE", "STORE_STATS", "MASK_STATS", "ATOMIC", "MASK_STATS_ATOMIC"};
+  return e >= 0 && e < 5 ? n[e] : "?";
+}
+
 int pick_split_k(long tiles, long kslabs, int slots) {
   // `slots` = workgroups resident on the chip at once (256 CUs x blocks/CU).  The grid runs in
   // ceil(blocks / slots) rounds; a last round that is mostly empty wastes up to one round, so among
@@ -1156,6 +1161,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
     }
     dim3 grid(cdiv(a.N, 48), cdiv(a.M, bm), sp);
     const int hl = cdiv(bm + 2 * (a.g.W + 1), 64);           // 256-pixel tiles: 5 (W <= 31) .. 8 (<= 127); 128-pixel tiles: 3, 4
+    RDM_CENSUS("conv3x3_halo_kernel/%s/px%d/hl%d/%s", halo_dgrad ? "dgrad" : "fwd", bm, small ? std::max(hl, 3) : std::max(hl, 5), epi_name(epi));
 #define RDM_HALO2(E_, D_)                                                                                       \
     if (small) {                                                                                                 \
       if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 3, D_, 2>), grid, dim3(256), 0, s, a);           \
@@ -1185,11 +1191,14 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
       a.N >= 512 && g_variant != 38) {
     dim3 grid(cdiv(a.N, 128), cdiv(a.M, 256), 1);
     const bool bn = a.a_scale != nullptr;
+    RDM_CENSUS("conv1x1_dma256_kernel/%s/bn%d", epi_name(epi), bn ? 1 : 0);
     if (epi == EPI_STORE) { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, false>), grid, dim3(256), 0, s, a); }
     else { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, false>), grid, dim3(256), 0, s, a); }
     RDM_LAUNCH_OK();
     return 0;
   }
+  RDM_CENSUS("conv_fwd_kernel/%s/%s/tile%s/%s", b_kstrided ? "dgrad" : "fwd", taps ? "taps" : "1x1",
+             cfg == 0 ? "256x48" : cfg == 1 ? "128x96" : cfg == 2 ? "64x96" : "128x48", epi_name(epi));
 #define RDM_FWD_DISPATCH(TAPS_, BKS_)                                                           \
   switch (epi) {                                                                               \
     case EPI_STORE: launch_fwd_epi<TAPS_, BKS_, EPI_STORE>(a, cfg, split, s); break;            \
@@ -1265,6 +1274,8 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   a.xcd_flat = g_variant == 11;
   ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
   prof.kind = row3 ? 6 : taps ? 5 : 4;
+  RDM_CENSUS("%s/%s/%s", row3 ? "conv_wgrad3_row_kernel" : taps ? "conv_wgrad_kernel/taps" : "conv_wgrad_kernel/1x1",
+             row3 ? "48x256x3" : few && !narrow ? "128x48" : few ? "48x128" : narrow ? "48x256" : tall ? "256x48" : "128x96", a.split_k > 1 ? "splitK" : "split1");
   if (row3) {
     a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
     const long padded = (a.n_items + 7) / 8 * 8;

@@ -51,6 +51,13 @@ constexpr int g_variant = 0;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launch census (rdm_census_*): while enabled, every MFMA launcher records WHICH kernel variant it picked (tile size, halo length,
+// epilogue, split) under a readable name, so the parity tests can assert that the variants the headline geometry selects were the
+// ones they compared with the oracle.  Off by default: one predictable branch per launch.
+extern bool g_census_on;
+void census_hit(const char* fmt, ...);
+#define RDM_CENSUS(...) do { if (::rdm::g_census_on) ::rdm::census_hit(__VA_ARGS__); } while (0)
+
 // ---------------------------------------------------------------------------------
 // internal launchers (igemm.hip) - the C-ABI conv entry points and the network plan
 // both go through these

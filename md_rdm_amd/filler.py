@@ -107,8 +107,8 @@ MARGIN_SEEDS = {"train228": 7, "eval226": 1, "train228x304": 10}
 DORN_MARGIN = 2.5e-4
 
 
-def dorn_unsafe_pairs(logits, thr=DORN_MARGIN):
-    """Number of (a, b) logit pairs whose ordinal decision could flip under a +-thr perturbation of both logits."""
+def dorn_safe_mask(logits, thr=DORN_MARGIN):
+    """(B, K, h, w) bool: True where the ordinal decision of the (a, b) logit pair cannot flip under a +-thr perturbation of both."""
     lg = np.asarray(logits, dtype=np.float64)
     a, b = lg[:, 0::2], lg[:, 1::2]
 
@@ -116,4 +116,9 @@ def dorn_unsafe_pairs(logits, thr=DORN_MARGIN):
         return np.clip(v, 1e-8, 1e4)
     always = (c(b - thr) - c(a + thr)) > 0
     never = (c(b + thr) - c(a - thr)) <= 0
-    return int((~(always | never)).sum())
+    return always | never
+
+
+def dorn_unsafe_pairs(logits, thr=DORN_MARGIN):
+    """Number of (a, b) logit pairs whose ordinal decision could flip under a +-thr perturbation of both logits."""
+    return int((~dorn_safe_mask(logits, thr)).sum())

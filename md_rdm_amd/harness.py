@@ -166,6 +166,11 @@ def find_learning_rate(model, opt, batches, min_lr=1e-8, max_lr=1.0, num_trainin
         loss.backward()
         opt.step(grad_scale=sync.finish() if sync is not None else 1.0)
         cur = float(loss.item())
+        if sync is not None:
+            # data parallel: the early stop below must be a COLLECTIVE decision.  Each rank's shard loss diverges at a different
+            # step near lr -> 1; a rank that left the sweep alone would leave the others blocked in the next stage all-reduce.
+            # Every rank smooths the rank-mean loss, so all of them run the same number of steps and suggest the same rate.
+            cur = sync.mean_scalar(cur)
         avg = beta * avg + (1 - beta) * cur
         smooth = avg / (1 - beta ** (i + 1))
         lrs.append(lr)

@@ -437,6 +437,8 @@ class DepthEstimationNet(BaseModel):
         table = (C.c_void_p * len(tensors))(*[t.data_ptr() if t.numel() else None for t in tensors])
         logits = torch.empty(B, 180, oh, ow, dtype=torch.float32, device=x.device)
         self._ws_generation += 1
+        if self.training:
+            self._bf16_stale = True                     # a training forward updates the running statistics the bf16 affines were folded from
         _lib.check(L.rdm_net_forward(h, _lib.ptr(x), table, C.c_void_p(self._ws.data_ptr()), ws_bytes, _lib.ptr(logits), int(self.training), _lib.stream()))
         self._last = (h, ws_bytes, table, tensors)
         self._last_batch = B

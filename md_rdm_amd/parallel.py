@@ -21,12 +21,39 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, flat_grad, slices, extra=(), group=None, buffers=(), flat_buffers=None):
-        self.flat, self.slices, self.extra, self.group = flat_grad, list(slices), list(extra), group
-        self.buffers = [b for b in buffers if b.numel()]
-        self.flat_buffers = list(flat_buffers) if flat_buffers else None     # contiguous storage behind `buffers` (one tensor per dtype)
+    def __init__(self, flat_grad, slices, extra=(), group=None, buffers=(), flat_buffers=None, on_buffers_changed=None):
+        """``flat_grad`` / ``buffers`` / ``flat_buffers``: tensors / tensor lists, or CALLABLES returning them - ``attach`` passes callables so that the
+        broadcast always sees the module's LIVE buffers (``flatten_parameters`` re-homes them after ``.to()`` / a re-flatten; a list
+        captured once would go on broadcasting the orphaned storage).  ``on_buffers_changed``: called after every buffer broadcast
+        (derived data such as the bf16 BatchNorm affines must be refreshed)."""
+        self._flat, self.slices, self.extra, self.group = flat_grad, list(slices), list(extra), group
+        self._buffers = buffers if callable(buffers) else [b for b in buffers if b.numel()]
+        self._flat_buffers = flat_buffers if callable(flat_buffers) else (list(flat_buffers) if flat_buffers else None)
+        self.on_buffers_changed = on_buffers_changed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles = []
+
+    @property
+    def flat(self):
+        return self._flat() if callable(self._flat) else self._flat
+
+    @property
+    def buffers(self):
+        return [b for b in self._buffers() if b.numel()] if callable(self._buffers) else self._buffers
+
+    @property
+    def flat_buffers(self):
+        fb = self._flat_buffers() if callable(self._flat_buffers) else self._flat_buffers
+        return list(fb) if fb else None
+
+    def mean_scalar(self, value):
+        """Mean over the ranks of a host scalar (one small all-reduce): every rank gets the SAME number, so control decisions taken
+        on it (the learning-rate finder's early stop) are taken together."""
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item()) / self.world
 
     def on_segment(self, stage):
         """Call right after backward stage ``stage`` has been enqueued."""
@@ -39,13 +66,17 @@ class GradSync:
 
     def sync_buffers(self):
         """torch DDP's ``broadcast_buffers``: every rank takes rank 0's BatchNorm running statistics / counters."""
-        if self.world == 1 or not self.buffers:
+        buffers = self.buffers
+        if self.world == 1 or not buffers:
             return
-        if self.flat_buffers is not None:                            # the model keeps its buffers in flat storage: broadcast in place
-            for buf in self.flat_buffers:
+        flat_buffers = self.flat_buffers
+        if flat_buffers is not None:                                 # the model keeps its buffers in flat storage: broadcast in place
+            for buf in flat_buffers:
                 dist.broadcast(buf, 0, group=self.group)
+            if self.on_buffers_changed is not None:
+                self.on_buffers_changed()
             return
-        floats = [b for b in self.buffers if b.dtype == torch.float32]
+        floats = [b for b in buffers if b.dtype == torch.float32]
         if floats:                                                   # one coalesced broadcast instead of ~480 tiny ones
             buf = torch.cat([b.reshape(-1) for b in floats])
             dist.broadcast(buf, 0, group=self.group)
@@ -53,7 +84,7 @@ class GradSync:
             for b in floats:
                 b.copy_(buf[o:o + b.numel()].view_as(b))
                 o += b.numel()
-        others = [b for b in self.buffers if b.dtype != torch.float32]
+        others = [b for b in buffers if b.dtype != torch.float32]
         if others:
             buf = torch.cat([b.reshape(-1).to(torch.int64) for b in others])
             dist.broadcast(buf, 0, group=self.group)
@@ -61,6 +92,8 @@ class GradSync:
             for b in others:
                 b.copy_(buf[o:o + b.numel()].view_as(b).to(b.dtype))
                 o += b.numel()
+        if self.on_buffers_changed is not None:
+            self.on_buffers_changed()
 
     def finish(self):
         """Wait for all reductions (and reduce the small extra tensors).  Gradients are SUMS;
@@ -91,8 +124,9 @@ def attach(model, group=None, broadcast_buffers=True):
         for p in model.weight_layer.parameters():
             if p.numel():
                 dist.broadcast(p.data, 0, group=group)
-    sync = GradSync(gflat, model.stage_slices(), extra=[p for p in model.weight_layer.parameters() if p.requires_grad], group=group,
-                    buffers=list(model.buffers()), flat_buffers=getattr(model, "_flat_buffers", None))
+    sync = GradSync(lambda: model._flat[1], model.stage_slices(), extra=[p for p in model.weight_layer.parameters() if p.requires_grad], group=group,
+                    buffers=lambda: list(model.buffers()), flat_buffers=lambda: getattr(model, "_flat_buffers", None),
+                    on_buffers_changed=getattr(model, "mark_weights_changed", None))
     model.direct_grads = True
     model.grad_ready_hook = sync.on_stage
     if broadcast_buffers and sync.world > 1:

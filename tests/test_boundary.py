@@ -186,6 +186,60 @@ def test_genuine_lightning_checkpoint_with_foreign_classes_loads_without_lightni
     assert checkpoint.restore_training_state(loaded, FakeOpt()) is False    # weights-only resume for reference checkpoints
 
 
+def test_hostile_checkpoint_pickle_executes_nothing(tmp_path):
+    """`--resume` on a crafted file.  A pickle whose __reduce__ names builtins.eval / exec / getattr / __import__,
+    os.system, subprocess or posix.system must have NO side effect through load_checkpoint_file: the stand-in unpickler resolves exact
+    (module, name) pairs only, everything else is inert.  The fallback path is forced (the weights_only pass refuses such a file)."""
+    import os
+    import pickle
+    import torch
+    from md_rdm_amd import checkpoint
+    marker = tmp_path / "pwned"
+    code = f"open({str(marker)!r}, 'w').write('x')"
+
+    class ViaEval:
+        def __reduce__(self):
+            return (eval, (code,))
+
+    class ViaExec:
+        def __reduce__(self):
+            return (exec, (code,))
+
+    class ViaSystem:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    class ViaImport:
+        def __reduce__(self):
+            return (__import__, ("os",))
+
+    class ViaGetattr:
+        def __reduce__(self):
+            return (getattr, (ViaImport(), "system"))
+
+    for i, evil in enumerate([ViaEval(), ViaExec(), ViaSystem(), ViaImport(), ViaGetattr()]):
+        path = tmp_path / f"evil{i}.ckpt"
+        payload = {"state_dict": {"model.weight_layer.d0": torch.ones(1, 1)}, "hyper_parameters": evil}
+        torch.save(payload, path)                                            # zip format
+        loaded = checkpoint.load_checkpoint_file(str(path))
+        assert not marker.exists(), type(evil).__name__
+        assert torch.equal(loaded["state_dict"]["model.weight_layer.d0"], torch.ones(1, 1))
+        assert isinstance(loaded["hyper_parameters"], checkpoint._Inert)
+        torch.save(payload, path, _use_new_zipfile_serialization=False)     # legacy format
+        checkpoint.load_checkpoint_file(str(path))
+        assert not marker.exists(), type(evil).__name__
+        with open(path, "wb") as fh:                                         # a bare protocol-4 pickle, the reproduction in the advice
+            pickle.dump({"x": evil}, fh, protocol=4)
+        try:
+            checkpoint.load_checkpoint_file(str(path))
+        except Exception:
+            pass                                                             # not a torch file: refusing it is fine, executing it is not
+        assert not marker.exists(), type(evil).__name__
+    allowed = checkpoint._allowed_globals()
+    assert not any(m == "builtins" and n in ("eval", "exec", "getattr", "__import__", "compile", "open", "setattr") for m, n in allowed)
+    assert not any(m.split(".")[0] in ("os", "posix", "subprocess", "sys", "importlib", "shutil") for m, n in allowed)
+
+
 def test_reduce_lr_on_plateau_matches_torch():
     """module.py:42-46: ReduceLROnPlateau(optimizer, 'max', patience=2) on val_delta1 - same lr trajectory as torch's scheduler."""
     import torch

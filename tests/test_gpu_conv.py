@@ -9,6 +9,19 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
+_RAN = set()          # headline-size parity cases that ran in this process (the census test at the end of the module needs all of them)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _census():
+    """Kernel-variant census for the whole module (rdm_census_*): the last test asserts that every variant the headline geometry
+    selects was launched by one of the oracle comparisons above it."""
+    from md_rdm_amd import _lib
+    L = _lib.lib()
+    L.rdm_census_reset()
+    L.rdm_census_enable(1)
+    yield
+    L.rdm_census_enable(0)
 
 
 def nhwc(t):
@@ -132,6 +145,239 @@ def test_conv1x1_big_grid(cin, cout):
         assert rel(dw[0].cpu().double(), gy.double().t() @ a) < TOL
 
 
+# ---------------------------------------------------------------------------------------------
+# Headline-size variants (B=16, 228x304: RDM_Net.py:526-530 shapes).  The dispatch in csrc/igemm.hip picks other kernels above certain
+# sizes - conv_wgrad3_row_kernel (>= 16 369 pixels), the 256-pixel conv3x3_halo_kernel tiles (> 8 192 pixels), conv1x1_dma256_kernel
+# (16 384 <= pixels < 32 768, >= 512 outputs) - and every one of them is compared here with a float64 torch-CPU evaluation of the same
+# operator (shifted-slice matmuls: the definition of the convolution, no library conv), through the C ABI, at 2e-5 of the tensor's max.
+# ---------------------------------------------------------------------------------------------
+def _ref3x3(a, w9):
+    """a (B,H,W,C) f64 (already normalised), w9 (9,N,C) f64 -> y (B*H*W, N): zero padding 1, stride 1."""
+    B, H, W, Cc = a.shape
+    ap = F.pad(a, (0, 0, 1, 1, 1, 1))
+    y = torch.zeros(B * H * W, w9.shape[1], dtype=torch.float64)
+    for r in range(3):
+        for q in range(3):
+            y += ap[:, r:r + H, q:q + W, :].reshape(-1, Cc) @ w9[r * 3 + q].t()
+    return y
+
+
+def _ref3x3_dgrad(gy, w9):
+    """gy (B,H,W,N) f64, w9 (9,N,C) -> dx (B*H*W, C)"""
+    B, H, W, N = gy.shape
+    gp = F.pad(gy, (0, 0, 1, 1, 1, 1))
+    dx = torch.zeros(B * H * W, w9.shape[2], dtype=torch.float64)
+    for r in range(3):
+        for q in range(3):
+            dx += gp[:, 2 - r:2 - r + H, 2 - q:2 - q + W, :].reshape(-1, N) @ w9[r * 3 + q]
+    return dx
+
+
+def _ref3x3_wgrad(gy, a):
+    B, H, W, N = gy.shape
+    Cc = a.shape[3]
+    ap = F.pad(a, (0, 0, 1, 1, 1, 1))
+    g2 = gy.reshape(-1, N).t().contiguous()
+    return torch.stack([g2 @ ap[:, r:r + H, q:q + W, :].reshape(-1, Cc) for r in range(3) for q in range(3)])
+
+
+ROW_WGRAD_CASES = [
+    # B, H, W, C, ld, N, bn      (>= 16 369 pixels and N <= 96 -> conv_wgrad3_row_kernel)
+    (4, 57, 76, 2736, 2736, 48, True),       # dense_e2 conv2 (RDM_Net.py:526): C = 10 x 256 + 176 (ragged channel tile)
+    (16, 29, 38, 1392, 1392, 48, True),      # dense_e3 conv2 at the bench batch (RDM_Net.py:528): C = 5 x 256 + 112
+    (3, 75, 73, 208, 272, 40, False),        # 16 425 pixels (not a multiple of 16: ragged last slab), C < 256, ld > C, N < 48
+    (5, 58, 57, 64, 64, 96, True),           # two 48-row tiles of output channels
+]
+
+
+@pytest.mark.parametrize("case", ROW_WGRAD_CASES, ids=[f"row{i}" for i in range(len(ROW_WGRAD_CASES))])
+def test_wgrad3_row_kernel_vs_float64(case):
+    """conv_wgrad3_row_kernel - the dominant kernel of the B=16 228x304 step - with its BN-ReLU prologue, ragged channel / row tiles,
+    ragged pixel tail, the launcher's own split (f32 atomics) and split_k = 1 (every element owned by one workgroup)."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cc, ld, N, bn = case
+    g = torch.Generator().manual_seed(1000 + Cc)
+    x = torch.randn(B, H, W, ld, generator=g)
+    x[..., Cc:] = float("nan")                                   # nothing behind the contracted prefix may be read into a product
+    gy = torch.randn(B, H, W, N, generator=g)
+    sc = torch.rand(Cc, generator=g) + 0.5
+    sh = torch.randn(Cc, generator=g) * 0.3
+    a = (torch.relu(x[..., :Cc] * sc + sh) if bn else x[..., :Cc]).double()
+    want = _ref3x3_wgrad(gy.double(), a)
+    d = ConvDesc(B, H, W, Cc, ld, N, N, 3, 3, 1, 1, 1, 1)
+    xg, gyg, scg, shg = x.to(dev), gy.to(dev), sc.to(dev), sh.to(dev)
+    before = _lib.census().get("conv_wgrad3_row_kernel/48x256x3/splitK", 0), _lib.census().get("conv_wgrad3_row_kernel/48x256x3/split1", 0)
+    for split in (0, 1, 7):
+        dw = torch.zeros(9, N, Cc, device=dev)
+        check(L.rdm_conv2d_wgrad_ex(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, stream()))
+        assert rel(dw.cpu().double(), want) < TOL, split
+    cen = _lib.census()
+    assert cen.get("conv_wgrad3_row_kernel/48x256x3/splitK", 0) >= before[0] + 2 and cen.get("conv_wgrad3_row_kernel/48x256x3/split1", 0) == before[1] + 1
+    _RAN.add(("row", case))
+
+
+HALO_CASES = [
+    # B, H, W, Cb (3x3 input channels), hl     (> 8 192 pixels -> 256-pixel halo tiles; hl = ceil((256 + 2(W+1)) / 64))
+    (9, 30, 31, 208, 5),
+    (8, 29, 38, 192, 6),                     # dense_e3's map (RDM_Net.py:528)
+    (2, 57, 76, 192, 7),                     # dense_e2's map (RDM_Net.py:526)
+    (1, 66, 127, 144, 8),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[f"hl{c[4]}" for c in HALO_CASES])
+def test_halo3x3_256px_forward_and_dgrad_vs_float64(case):
+    """conv3x3_halo_kernel<.., HL = 5..8, .., MT = 4> (256-pixel tiles), forward and dgrad, every epilogue: STORE, STORE_STATS (train-mode
+    statistics), ATOMIC (K-split), MASK_STATS and MASK_STATS_ATOMIC (ReLU gate + BatchNorm-backward sums); ragged last pixel tile,
+    image borders and batch wrap-around inside a tile, ragged channel tile of the dgrad (Cb not a multiple of 48)."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cb, hl = case
+    N, M = 48, B * H * W
+    assert M > 8192
+    g = torch.Generator().manual_seed(2000 + W)
+    ld = Cb + 16
+    y = torch.randn(B, H, W, ld, generator=g)
+    y[..., Cb:] = float("nan")
+    w = torch.randn(9, N, Cb, generator=g) / (9 * Cb) ** 0.5
+    sc = torch.rand(Cb, generator=g) + 0.5
+    sh = torch.randn(Cb, generator=g) * 0.3
+    z = y[..., :Cb] * sc + sh
+    a = torch.relu(z).double()
+    want = _ref3x3(a, w.double())
+    d = ConvDesc(B, H, W, Cb, ld, N, N, 3, 3, 1, 1, 1, 1)
+    yg, wg, scg, shg = y.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    for split, stats in ((1, False), (0, True), (0, False), (4, False)):        # STORE | STORE_STATS | launcher's split | ATOMIC
+        out = torch.full((M, N), float("nan"), device=dev)
+        ssum = torch.zeros(N, dtype=torch.float64, device=dev)
+        ssq = torch.zeros_like(ssum)
+        check(L.rdm_conv2d_fwd_ex(C.byref(d), ptr(yg), ptr(wg), None, ptr(scg), ptr(shg), ptr(out), ptr(ssum) if stats else None,
+                                  ptr(ssq) if stats else None, split, stream()))
+        assert rel(out.cpu().double(), want) < TOL, (split, stats)
+        if stats:
+            assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+    # dgrad of the same conv: dY[m][c] = sum_taps dOut[..][n] w[tap][n][c], gated by relu'(z), with sum dY and sum dY*y per channel
+    go = torch.randn(B, H, W, N, generator=g)
+    gog = go.to(dev)
+    dx_ref = _ref3x3_dgrad(go.double(), w.double())
+    gate = (z > 0).reshape(M, Cb).double()
+    y2 = y[..., :Cb].reshape(M, Cb).double()
+    for split, mask in ((1, False), (1, True), (3, False), (3, True)):          # STORE | MASK_STATS | ATOMIC | MASK_STATS_ATOMIC
+        dx = torch.full((M, Cb), float("nan"), device=dev)
+        s0 = torch.zeros(Cb, dtype=torch.float64, device=dev)
+        s1 = torch.zeros_like(s0)
+        check(L.rdm_conv2d_dgrad_ex(C.byref(d), ptr(gog), ptr(wg), ptr(dx), Cb, ptr(yg) if mask else None, ld, ptr(scg) if mask else None,
+                                    ptr(shg) if mask else None, ptr(s0) if mask else None, ptr(s1) if mask else None, split, stream()))
+        ref = dx_ref * gate if mask else dx_ref
+        assert rel(dx.cpu().double(), ref) < TOL, (split, mask)
+        if mask:
+            assert rel(s0.cpu(), ref.sum(0)) < 1e-5 and rel(s1.cpu(), (ref * y2).sum(0)) < 1e-5
+    cen = _lib.census()
+    for name in ("fwd/px256/hl%d/STORE", "fwd/px256/hl%d/STORE_STATS", "fwd/px256/hl%d/ATOMIC", "dgrad/px256/hl%d/STORE", "dgrad/px256/hl%d/MASK_STATS",
+                 "dgrad/px256/hl%d/ATOMIC", "dgrad/px256/hl%d/MASK_STATS_ATOMIC"):
+        assert cen.get("conv3x3_halo_kernel/" + name % hl, 0) >= 1, (name % hl, sorted(cen))
+    _RAN.add(("halo", case))
+
+
+@pytest.mark.parametrize("cout", [1392, 528])
+@pytest.mark.parametrize("cin", [192, 240, 720, 912])
+def test_conv1x1_dma256_kernel_vs_float64(cin, cout):
+    """conv1x1_dma256_kernel (16 384 <= pixels < 32 768, >= 512 outputs: dense_e3's bottleneck, RDM_Net.py:528) vs an f64 matmul:
+    K a multiple of 32 (192) and with a 16-channel tail (240, 720, 912), ragged last pixel tile (17 632 = 68 x 256 +
+    224) and channel tile (1392 = 10 x 128 + 112, 528 = 4 x 128 + 16), BN-ReLU coefficients by DMA on / off, STORE and STORE_STATS, and NaN
+    in the channels BEHIND the contracted prefix of the input buffer."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W = 16, 29, 38
+    M, ld = B * H * W, cin + 48
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(M, ld, generator=g)
+    x[:, cin:] = float("nan")
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    d = ConvDesc(B, H, W, cin, ld, cout, cout, 1, 1, 1, 1, 0, 0)
+    xg, wg, scg, shg = x.to(dev), w.to(dev).view(1, cout, cin).contiguous(), sc.to(dev), sh.to(dev)
+    for bn in (True, False):
+        a = (torch.relu(x[:, :cin] * sc + sh) if bn else x[:, :cin]).double()
+        want = a @ w.double().t()
+        for stats in (True, False):
+            key = "conv1x1_dma256_kernel/%s/bn%d" % ("STORE_STATS" if stats else "STORE", int(bn))
+            before = _lib.census().get(key, 0)
+            y = torch.full((M, cout), float("nan"), device=dev)
+            ssum = torch.zeros(cout, dtype=torch.float64, device=dev)
+            ssq = torch.zeros_like(ssum)
+            # split_k = 1: what the statistics epilogue runs with anyway (the plan's 12 launches per step); without it the launcher
+            # may split the short-N case (528 outputs) over K, which is conv_fwd_kernel's business
+            check(L.rdm_conv2d_fwd_ex(C.byref(d), ptr(xg), ptr(wg), None, ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(y),
+                                      ptr(ssum) if stats else None, ptr(ssq) if stats else None, 1, stream()))
+            assert _lib.census().get(key, 0) == before + 1, key                 # the kernel under test is the one that ran
+            assert rel(y.cpu().double(), want) < TOL, (bn, stats)
+            if stats:
+                assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+    _RAN.add(("dma256", cin, cout))
+
+
+@pytest.mark.parametrize("cin", [96, 288])
+def test_conv1x1_big_grid_dgrad_and_small_grid_split(cin):
+    """The 1x1 dgrad of dense_e2's bottleneck (RDM_Net.py:526; > 32 768 pixels, N = cin a multiple of 96 -> 128 x 96 tiles) with the
+    ReLU gate + BatchNorm-backward sums, unsplit (MASK_STATS) and K-split (MASK_STATS_ATOMIC, ATOMIC); and the K-split 1x1 forward on
+    128 x 48 tiles (dense_e4 / decoder: conv1 'part A' accumulates atomically, net.hip forward_block) - all vs float64 matmuls."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, cb = 11, 57, 57, 2736
+    M, ld = B * H * W, cin + 96
+    g = torch.Generator().manual_seed(31 + cin)
+    dz = torch.randn(M, cb, generator=g)
+    w = torch.randn(cb, cin, generator=g) / cb ** 0.5
+    x = torch.randn(M, ld, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    want = dz.double() @ w.double()
+    gate = ((x[:, :cin] * sc + sh) > 0).double()
+    d = ConvDesc(B, H, W, cin, ld, cb, cb, 1, 1, 1, 1, 0, 0)
+    dzg, wg, xg, scg, shg = dz.to(dev), w.to(dev).view(1, cb, cin).contiguous(), x.to(dev), sc.to(dev), sh.to(dev)
+    for split, mask in ((1, True), (3, True), (1, False), (3, False)):
+        dx = torch.full((M, cin), float("nan"), device=dev)
+        s0 = torch.zeros(cin, dtype=torch.float64, device=dev)
+        s1 = torch.zeros_like(s0)
+        check(L.rdm_conv2d_dgrad_ex(C.byref(d), ptr(dzg), ptr(wg), ptr(dx), cin, ptr(xg) if mask else None, ld, ptr(scg) if mask else None,
+                                    ptr(shg) if mask else None, ptr(s0) if mask else None, ptr(s1) if mask else None, split, stream()))
+        ref = want * gate if mask else want
+        assert rel(dx.cpu().double(), ref) < TOL, (split, mask)
+        if mask:
+            assert rel(s0.cpu(), ref.sum(0)) < 1e-5 and rel(s1.cpu(), (ref * x[:, :cin].double()).sum(0)) < 1e-5
+    cen = _lib.census()
+    for e in ("MASK_STATS", "MASK_STATS_ATOMIC", "STORE", "ATOMIC"):
+        assert cen.get("conv_fwd_kernel/dgrad/1x1/tile128x96/" + e, 0) >= 1, (e, sorted(cen))
+    # K-split forward at dense_e4's size: 4 560 pixels, K = 1056 + cin, 720 outputs
+    Bs, Hs, Ws, K, N = 16, 15, 19, 1056 + cin, 720
+    Ms = Bs * Hs * Ws
+    xs = torch.randn(Ms, K, generator=g)
+    ws = torch.randn(N, K, generator=g) / K ** 0.5
+    scs = torch.rand(K, generator=g) + 0.5
+    shs = torch.randn(K, generator=g) * 0.3
+    wants = torch.relu(xs * scs + shs).double() @ ws.double().t()
+    ds = ConvDesc(Bs, Hs, Ws, K, K, N, N, 1, 1, 1, 1, 0, 0)
+    for split in (1, 4, 0):
+        y = torch.full((Ms, N), float("nan"), device=dev)
+        check(L.rdm_conv2d_fwd_ex(C.byref(ds), ptr(xs.to(dev)), ptr(ws.to(dev).view(1, N, K).contiguous()), None, ptr(scs.to(dev)), ptr(shs.to(dev)),
+                                  ptr(y), None, None, split, stream()))
+        assert rel(y.cpu().double(), wants) < TOL, split
+    cen = _lib.census()
+    assert cen.get("conv_fwd_kernel/fwd/1x1/tile128x48/ATOMIC", 0) >= 1 and cen.get("conv_fwd_kernel/fwd/1x1/tile128x48/STORE", 0) >= 1
+    _RAN.add(("dgrad_big", cin))
+
+
 def test_conv_linearity_full_size():
     """Size-independent property at the bench geometry (B=16, 57x76, 96->2736): conv(a*x1+b*x2) == a*conv(x1)+b*conv(x2)."""
     from md_rdm_amd import _lib
@@ -178,3 +424,30 @@ def test_fused_adamw_matches_torch():
         opt.step()
         check(L.rdm_adamw_fused(ptr(pg), ptr(gr.to(dev)), ptr(m), ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, step, 1.0, stream()))
     assert rel(pg.cpu(), p.detach()) < 1e-6
+
+
+def test_every_headline_kernel_variant_was_launched_by_a_parity_test():
+    """Self-checking coverage.  Run one B=16 228x304 train step (the bench geometry) with the census on and collect the kernel VARIANTS
+    the plan selects; every one of them must already have been launched by an oracle comparison of this module (the census is reset
+    when the module starts and the whole-step launches are counted separately).  Skipped when the module was only run in part."""
+    from md_rdm_amd import _lib, filler, harness
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    need = len(ROW_WGRAD_CASES) + len(HALO_CASES) + 8 + 2
+    if len(_RAN) < need:
+        pytest.skip(f"only {len(_RAN)} of {need} headline parity cases ran in this process")
+    L = _lib.lib()
+    by_tests = _lib.census()
+    L.rdm_census_reset()
+    dev = torch.device("cuda:0")
+    m = DepthEstimationNet()
+    filler.fill_state_dict(m.state_dict())
+    m = m.to(dev).train()
+    x, y = filler.synthetic_batch(16, 228, 304, seed=1234)
+    loss, _ = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    step = _lib.census()
+    assert len(step) >= 10 and any(k.startswith("conv_wgrad3_row_kernel") for k in step) and any("px256" in k for k in step) and any(
+        k.startswith("conv1x1_dma256_kernel") for k in step), sorted(step)
+    missing = sorted(k for k in step if by_tests.get(k, 0) == 0)
+    assert not missing, "kernel variants of the headline step that no parity test launched: %r" % missing

@@ -249,6 +249,68 @@ def test_fused_adamw_leaves_frozen_encoder_bit_identical(dev):
     assert moved > 90                                              # the decoder (24 layers x 6 tensors + conv2) and the 4 scalars train
 
 
+def test_train_step_b16_228x304_vs_oracle(dev):
+    """The BENCH geometry itself (BASELINE configs[2]: B=16, 228x304, full train step) against the CPU oracle on the same seeded
+    batch - the step that selects conv_wgrad3_row_kernel, the 256-pixel halo tiles and conv1x1_dma256_kernel.  Forward: block taps
+    rtol 1e-4, logits 2e-4 of their max, probabilities 2e-4, losses 1e-4, ordinal indices equal wherever the oracle's decision has
+    the +-2.5e-4 margin (this input was not margin-searched; the unsafe pairs are counted and bounded).  Backward: the per-tensor
+    criterion of the B=2 test - relative L2 error against the float64 oracle <= 2 x that tensor's own float32-oracle error + 1.5e-2,
+    gradient norm against the float64 oracle's <= 3 x the float32 oracle's own norm error + 1.5e-3 (or the geometric bound)."""
+    import time
+    from md_rdm_amd import harness
+    B, H, W = 16, 228, 304
+    x, y = filler.synthetic_batch(B, H, W, seed=1234)
+    m = make_model(dev)
+    loss, parts = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    taps = {}
+    r32 = onet.training_step(onet.new_state_dict(filler.state_value), torch.from_numpy(x), y, taps=taps)
+    t1 = time.time()
+    for tap, (buf, c) in TAPS.items():
+        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
+        np.testing.assert_allclose(stats3(m.debug_buffer(buf).view(-1, ctot)[:, :c]), taps[tap], rtol=1e-4, atol=1e-6, err_msg=tap)
+    P = parts["ord_label_pred"].detach().cpu().numpy()
+    dec = parts["ord_depth_pred"].cpu().numpy()
+    np.testing.assert_allclose(P, r32["P"], atol=2e-4)
+    safe = filler.dorn_safe_mask(r32["logits"])                                # pair decisions that survive +-2.5e-4 on both logits
+    assert safe.mean() > 0.99
+    np.testing.assert_array_equal(((P > 0.5) & safe).sum(1, keepdims=True), ((r32["P"] > 0.5) & safe).sum(1, keepdims=True))
+    assert np.abs(dec - r32["decode"]).max() <= int((~safe).sum(1).max())      # a count can only differ by its unsafe pairs
+    np.testing.assert_array_equal(parts["ord_y"].cpu().numpy(), r32["ord_y"])
+    got = np.array([parts["mse"].item(), parts["fine_detail_loss"].item(), parts["ord_loss"].item(), loss.item()])
+    if np.array_equal(dec, r32["decode"]):                                      # the mse / fine-detail terms are functions of the integer counts
+        np.testing.assert_allclose(got, [r32["mse"], r32["fine_detail_loss"], r32["ord_loss"], r32["loss_all"]], rtol=1e-4)
+    np.testing.assert_allclose(got[2], r32["ord_loss"], rtol=1e-4)
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in onet.new_state_dict(filler.state_value).items()}
+    r64 = onet.training_step(sd64, torch.from_numpy(x).double(), y)
+    t2 = time.time()
+    print(f"[b16 oracle] f32 {t1 - t0:.1f} s, f64 {t2 - t1:.1f} s")
+    K_L2, FLOOR_L2, K_NORM, FLOOR_NORM = 2.0, 1.5e-2, 3.0, 1.5e-3
+    report = []
+    for n, p in m.named_parameters():
+        g64 = r64["grads"].get(n)
+        if g64 is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            continue
+        if n.startswith("weight_layer.") and not np.array_equal(dec, r32["decode"]):
+            continue                                                            # the 4 scalars see the counts, not the logits
+        g, g32 = p.grad.cpu().double(), r32["grads"][n].double()
+        n64 = g64.norm().item() + 1e-300
+        report.append((n, (g - g64).norm().item() / n64, (g32 - g64).norm().item() / n64, abs(g.norm().item() - n64) / n64,
+                       abs(g32.norm().item() - n64) / n64, p.numel()))
+    assert len(report) >= 481
+    import os
+    if os.environ.get("RDM_GRAD_REPORT"):
+        import json
+        with open(os.environ["RDM_GRAD_REPORT"] + ".b16", "w") as fh:
+            json.dump(report, fh)
+    bad = [t for t in report if t[1] > K_L2 * t[2] + FLOOR_L2 or t[3] > max(K_NORM * t[4] + FLOOR_NORM, t[1] * 4.0 / t[5] ** 0.5 + t[1] ** 2)]
+    assert not bad, "per-tensor gradient parity failed for %d tensors (name, l2 hip, l2 f32, norm hip, norm f32, numel): %r" % (
+        len(bad), sorted(bad, key=lambda t: -t[1])[:5])
+
+
 def test_full_size_properties_b16_228x304(dev):
     """BASELINE geometry (too slow for the CPU oracle): per-sample independence in eval mode,
     P in [0,1], decode == #{P > 0.5}, finite loss/gradients for a full train step."""

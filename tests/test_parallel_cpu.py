@@ -54,6 +54,89 @@ def test_gradsync_world2_gloo():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _lr_worker(rank, world, port, q):
+    """find_learning_rate under data parallelism: the shard losses of the two ranks diverge at DIFFERENT sweep
+    steps.  Every step runs a collective (the stage all-reduces, here one all_reduce in finish()); if one rank left the sweep
+    alone, the other would block in it and this worker would never report."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from md_rdm_amd import harness
+    from md_rdm_amd.parallel import GradSync
+
+    class Opt:
+        lr, m, v = 1e-4, None, None
+
+        class small:
+            param_groups = [{"lr": 1e-4}]
+
+        def zero_grad(self): pass
+        def step(self, grad_scale=1.0): self.scale = grad_scale
+        def state_dict(self): return {"exp_avg": None}
+        def load_state_dict(self, sd): pass
+
+    class Model:
+        _flat = (torch.zeros(8), torch.zeros(8), [])
+        def state_dict(self): return {}
+        def mark_weights_changed(self): pass
+
+    opt, steps = Opt(), []
+    blow_at = 40 if rank == 0 else 70                               # rank 0's shard diverges 30 steps before rank 1's
+
+    def fake_step(model, x, y):
+        i = len(steps)
+        steps.append(i)
+        return torch.tensor(1.0 / (1 + 0.05 * i) if i < blow_at else 50.0 * (i - blow_at + 1), requires_grad=True), {}
+    harness.training_step = fake_step
+    sync = GradSync(Model._flat[1], [(0, 8)], group=None)
+    real_finish = sync.finish
+
+    def finish():
+        sync.on_segment(0)                                           # the per-step gradient exchange every rank must take part in
+        return real_finish()
+    sync.finish = finish
+    lr, lrs, losses = harness.find_learning_rate(Model(), opt, iter([(None, None)] * 100), sync=sync)
+    q.put((rank, len(steps), lr, losses[-1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_find_learning_rate_stops_collectively_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_lr_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=90) for _ in ps)
+    finally:
+        for p in ps:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()                                             # a rank blocked in a collective: exactly the failure this test is about
+    (r0, n0, lr0, l0), (r1, n1, lr1, l1) = res
+    assert (r0, r1) == (0, 1)
+    assert n0 == n1 and 40 < n0 < 100                                # same number of steps on both ranks, stopped early
+    assert lr0 == lr1 and lr0 is not None and abs(l0 - l1) < 1e-12   # same smoothed (rank-mean) loss, same suggestion
+
+
+def test_gradsync_rereads_the_models_live_buffers_after_a_reflatten():
+    """attach() hands GradSync CALLABLES, so buffers / gradients re-homed by a later flatten_parameters() are the ones
+    that get broadcast / reduced - not the storage captured at attach time."""
+    from md_rdm_amd.parallel import GradSync
+
+    class M:
+        pass
+    m = M()
+    m.bufs, m.flat_bufs, m.g = [torch.zeros(3)], [torch.zeros(3)], torch.zeros(4)
+    s = GradSync(lambda: m.g, [(0, 4)], buffers=lambda: m.bufs, flat_buffers=lambda: m.flat_bufs)
+    first = (s.buffers[0], s.flat_buffers[0], s.flat)
+    m.bufs, m.flat_bufs, m.g = [torch.ones(3)], [torch.ones(3)], torch.ones(4)          # "re-flattened"
+    assert s.buffers[0] is m.bufs[0] and s.flat_buffers[0] is m.flat_bufs[0] and s.flat is m.g
+    assert first[0] is not s.buffers[0] and first[2] is not s.flat
+
+
 def test_gradsync_single_process_is_noop():
     from md_rdm_amd.parallel import GradSync
     flat = torch.ones(10)
