@@ -132,6 +132,16 @@ int rdm_conv2d_dgrad_ex(const rdm_conv_desc* d, const float* dy, const float* w_
 int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 
+/* The 3x3 / stride 1 / pad 1 convolution with <= 48 outputs (torchvision _DenseLayer.conv2 reached from network/RDM_Net.py:144,526-530)
+ * as Winograd F(2x2, 3x3) on the f32 MFMA path: 2.25x fewer multiply-adds than rdm_conv2d_fwd for the same result up to float32
+ * rounding (tests/test_gpu_wino.py holds it to the same 2e-5 against a float64 evaluation).  Same operands and meaning as
+ * rdm_conv2d_fwd (w_packed [9][out_c][in_c], BatchNorm + ReLU prologue, zero padding after it, optional channel statistics); the
+ * workspace (rdm_conv3x3_wino_workspace_bytes, 256-byte aligned) holds the transformed weights and, for a K-split, the per-split
+ * partial outputs, which are summed in a FIXED order (no atomics: the result is bit-reproducible).  split_k = 0: the launcher's choice. */
+size_t rdm_conv3x3_wino_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k);
+int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
+                         double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream);
+
 /* [out][in][kh][kw] (PyTorch) <-> [tap][out_pad][in] (packed); rows >= out_c are zero-filled. */
 int rdm_pack_conv_weight(const float* w_oihw, float* w_packed, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,
                          int32_t out_c_padded, rdm_stream_t stream);

@@ -10,6 +10,7 @@
 #include "rdm_common.h"
 #include "elementwise.h"
 #include "bf16.h"
+#include "wino.h"
 
 namespace rdm {
 long long g_launches = 0;
@@ -183,6 +184,37 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.split_k = split_k;
   return launch_conv_wgrad(a, stream);
+}
+
+size_t rdm_conv3x3_wino_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k) {
+  if (channels <= 0 || channels % 16 || batch <= 0 || h <= 0 || w <= 0 || split_k < 0) return 0;
+  const int T = batch * ((h + 1) / 2) * ((w + 1) / 2);
+  const int split = split_k > 0 ? split_k : wino_pick_split(T, channels / 16);
+  return wino_fwd_workspace_bytes(channels, (long)batch * h * w, split);
+}
+
+int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y,
+                         double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream) {
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(x && w && y && workspace, "conv3x3_wino_fwd: NULL operand");
+  RDM_CHECK_ARG(d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1, "conv3x3_wino_fwd: 3x3 / stride 1 / pad 1 only");
+  RDM_CHECK_ARG(d->out_c <= 48 && d->in_c % 16 == 0, "conv3x3_wino_fwd: out_c (%d) <= 48 and in_c (%d) a multiple of 16", d->out_c, d->in_c);
+  RDM_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr) && (stat_sum == nullptr) == (stat_sq == nullptr), "conv3x3_wino_fwd: scale/shift and the two statistics go together");
+  RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && split_k >= 0, "conv3x3_wino_fwd: workspace must be 256-byte aligned, split_k >= 0");
+  const long M = (long)d->batch * d->in_h * d->in_w;
+  const size_t ub = (((size_t)16 * 48 * d->in_c * sizeof(float)) + 255) & ~(size_t)255;
+  if (workspace_bytes < ub) { set_error("conv3x3_wino_fwd: workspace too small: %zu < %zu", workspace_bytes, ub); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  float* U = static_cast<float*>(workspace);
+  if ((rc = launch_wino_weight(w, (long)d->out_c * d->in_c, d->in_c, d->out_c, d->in_c, U, stream))) return rc;
+  WinoConv a{};
+  a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift; a.U = U;
+  a.out = y; a.ldc = d->out_ld; a.N = d->out_c; a.B = d->batch; a.H = d->in_h; a.W = d->in_w;
+  a.split = split_k; a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ub); a.partial_floats = (workspace_bytes - ub) / sizeof(float);
+  if (a.partial_floats < (size_t)M * 48 * 2) { a.partial = nullptr; a.partial_floats = 0; }
+  a.stat0 = stat_sum; a.stat1 = stat_sq;
+  return launch_conv3x3_wino_fwd(a, stream);
 }
 
 int rdm_pack_conv_weight(const float* w, float* wp, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw, int32_t out_c_padded, rdm_stream_t stream) {

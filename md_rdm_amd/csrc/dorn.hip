@@ -101,8 +101,10 @@ __global__ void k_depth2label_sid(const double* __restrict__ d, int* __restrict_
   if (i >= n) return;
   const double alpha = 0x1.47ae14p-6, den = 0x1.8dbc24p+2;
   double l = 90.0 * log(d[i] / alpha) / den;
-  l = fmax(l, 0.0);            // NaN (d < 0) propagates like torch.max -> int conversion is UB in both; d > 0 by construction
-  label[i] = (int)l;
+  // d <= 0 happens (a bicubic-resized target overshoots below zero next to an invalid pixel): log gives NaN, torch.max PROPAGATES it
+  // (C fmax would not) and the reference's `.int()` of NaN on the CPU - the machine the parity fixtures were generated on - is x86's
+  // "integer indefinite" 0x80000000.  The ordinal loss then sees a label below every index (all 90 pairs on the `k > t` side).
+  label[i] = (l != l) ? (int)0x80000000 : (int)fmax(l, 0.0);
 }
 
 }  // namespace rdm

@@ -1,0 +1,20 @@
+// internal launcher declarations (wino.hip): Winograd F(2x2, 3x3) for the 48-output 3x3 convolutions of the dense layers
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+namespace rdm {
+struct WinoConv {
+  const float* A; int lda; int C;                 // raw NHWC input (pre BatchNorm), contracted channels (multiple of 16)
+  const float* a_scale; const float* a_shift;     // consumer BatchNorm + ReLU, per contracted channel (NULL: identity)
+  const float* U;                                 // launch_wino_weight output, 16 * 48 * C floats
+  float* out; int ldc; int N;                     // output slice (pixel stride ldc), N <= 48 channels
+  int B, H, W;
+  int split;                                      // 0: launcher's choice; > 1 needs `partial`
+  float* partial; size_t partial_floats;          // scratch for the per-split partial outputs, split * B*H*W * 48 floats
+  double* stat0; double* stat1;                   // optional: += sum / sum of squares of the output per channel
+};
+size_t wino_fwd_workspace_bytes(int C, long M, int split);
+int wino_pick_split(int tiles, int nslab);
+int launch_wino_weight(const float* w_packed, long wtap, int ldw, int N, int C, float* U, hipStream_t s);
+int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s);
+}  // namespace rdm

@@ -1,0 +1,371 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions of the dense layers (48 outputs, K = 9 * Cb), exact-f32 MFMA.
+//
+// Replaces, for the layers with many pixels (dense_e2 / dense_e3: network/RDM_Net.py:526,528), the direct implicit GEMM of
+// csrc/igemm.hip (conv3x3_halo_kernel): the reference's nn.Conv2d(bn_size*growth, growth, 3, padding=1) inside torchvision's
+// _DenseLayer.  The 3x3 convolutions are 54 % of the network's multiply-adds; F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input
+// patch with 16 multiplies per (input channel, output channel) instead of 36 - 2.25x fewer MFMAs for the same result:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray; B^T, G, A^T below)
+// The float32 error of this form is ~2x the direct f32 sum's (measured 6e-7 of the output's max at K = 24 624), far inside the 2e-5
+// operator tolerance and the 1e-4 parity bar.
+//
+// MI355X mapping (not a cuDNN translation):
+//  * the 16 transform positions are 16 INDEPENDENT GEMMs  M_pos[tile][n] = sum_c V_pos[tile][c] * U_pos[n][c]; a 512-thread workgroup
+//    (8 wave64s, one per CU: two per SIMD) owns 64 tiles (256 output pixels) x 48 channels, wave w owns positions 2w, 2w+1: 2 x (4 x 3)
+//    MFMA tiles = 96 accumulator registers, and no two waves ever need the same operand fragment.
+//  * U (the transformed weights) never touches LDS: it is stored in HBM in FRAGMENT order [slab][pos][n-tile][lane][4] by a tiny
+//    transform kernel, so a wave's B fragment is one fully coalesced 1-KiB global_load_dwordx4 (L2 resident: 48 KB per slab, shared
+//    by every workgroup).
+//  * V (the transformed activations) is formed in registers: thread (tile, channel pair) gathers its 4x4 patch with 16 buffer loads
+//    (hardware range check = zero padding outside the tensor), applies the consumer BatchNorm + ReLU, masks the zero-padded positions,
+//    runs the two 1-D transforms in place (64 adds) and writes 16 x 8 bytes into a double-buffered, chunk-swizzled LDS image
+//    [pos][tile][16 k]: ONE barrier per 16-channel slab.  A fragments are conflict-free ds_read_b128 (4 consecutive k per lane; the
+//    k permutation is shared with the B fragments).
+//  * split-K writes per-split partial OUTPUTS (the output transform is linear) with plain stores; a small ordered reduction adds them
+//    in a fixed order and takes the per-channel statistics of the sum - deterministic, and 5x the byte rate of f32 atomics.
+#include <algorithm>
+
+#include "rdm_common.h"
+#include "elementwise.h"
+#include "wino.h"
+
+namespace rdm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned WOOB = 0xFFFFFFFFu;
+constexpr int TT = 64;                 // tiles per workgroup
+constexpr int LDM = 52;                // epilogue image [pos][32 tiles][LDM]: 4 * LDM = 16 mod 32 -> the four k-groups of a store hit disjoint banks
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsrd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// chunk swizzle of the [row][16 floats] LDS image: the 16-byte chunk c of row r sits in slot c ^ f(r), f by (r >> 2) & 3 = {0, 2, 3, 1}.
+// With the ds_read_b128 lane groups of gfx950 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; MI355X_MICROARCH.md, LDS) the 16 lanes of
+// a group then cover all 16 chunk slots of the 256-byte bank row (checked exhaustively by tools/wino_lds_check.py).
+__device__ __forceinline__ int swz(int row) { return (0x78 >> ((row >> 1) & 6)) & 3; }      // {0,2,3,1}[(row >> 2) & 3] packed as 0b01'11'10'00
+
+// ---------------------------------------------------------------------------------------------
+// weight transform  U = G g G^T  ->  fragment order [slab][pos][nt][lane = g*16 + l16][e]:  n = nt*16 + l16, c = slab*16 + 4*g + e
+// (w_packed is [tap = r*3 + q][n][c], `flip` reads tap (2-r)*3 + (2-q): the dgrad correlation)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w, long wtap, int ldw, int N, int C, float* __restrict__ U) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per (slab, nt, lane): produces 16 positions x 4 e
+  const int lane = (int)(idx & 63);
+  const long r1 = idx >> 6;
+  const int nt = (int)(r1 % 3), slab = (int)(r1 / 3);
+  if (slab >= C / 16) return;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int n = nt * 16 + l16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = slab * 16 + 4 * g + e;
+    float gg[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) gg[r][q] = n < N ? w[(long)(r * 3 + q) * wtap + (long)n * ldw + c] : 0.f;
+    float t[4][3];                                               // G g
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      t[0][q] = gg[0][q];
+      t[1][q] = 0.5f * (gg[0][q] + gg[1][q] + gg[2][q]);
+      t[2][q] = 0.5f * (gg[0][q] - gg[1][q] + gg[2][q]);
+      t[3][q] = gg[2][q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+      const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) U[((((long)slab * 16 + (i * 4 + j)) * 3 + nt) * 64 + lane) * 4 + e] = u[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------------------------
+struct WinoFwdArgs {
+  const float* A; int lda; int C;                 // raw NHWC input, contracted channels (multiple of 16)
+  const float* a_scale; const float* a_shift;     // consumer BatchNorm + ReLU (may be NULL)
+  const float* U;                                 // transformed weights, fragment order
+  float* out; int ldc; int N;                     // split == 1: the output slice itself;  split > 1: partial[split][M][48]
+  int B, H, W, TH, TW, T;                         // T = B * TH * TW tiles
+  int split;
+  unsigned a_bytes;
+};
+
+template <bool BNRELU>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_fwd_kernel(WinoFwdArgs p) {
+  __shared__ __attribute__((aligned(1024))) float smem[2 * 16 * TT * 16];        // V double buffer: 2 x 64 KB; reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int nslab = p.C / 16;
+  int s_begin = 0, s_end = nslab;
+  if (p.split > 1) {
+    const int per = (nslab + p.split - 1) / p.split;
+    s_begin = blockIdx.y * per;
+    s_end = min(nslab, s_begin + per);
+  }
+  const int tile0 = blockIdx.x * TT;
+
+  // ---- staging role: thread -> (tile tl, channel pair cp) ----
+  const int tl = tid >> 3, cp = tid & 7;
+  unsigned voff[16];
+  {
+    const int t = tile0 + tl;
+    const bool tok = t < p.T;
+    const int tpi = p.TH * p.TW;
+    const int b = t / tpi, rem = t - b * tpi;
+    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+        const bool ok = tok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        voff[i * 4 + j] = ok ? (unsigned)((b * p.H + y) * p.W + x) * (unsigned)(p.lda * 4) + (unsigned)(cp * 8) : WOOB;
+      }
+  }
+  const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
+  const int vrow = tl, vslot_base = cp >> 1, vhalf = cp & 1;
+  f32x2 raw[16];
+  auto load_raw = [&](int s) {
+    const unsigned so = (unsigned)(s * 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(srdA, (int)(voff[q] == WOOB ? WOOB : voff[q] + so), 0, 0);
+      raw[q] = f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+    }
+  };
+  // BatchNorm + ReLU of the consumer, zero for the padded positions, then V = B^T d B in place, then 16 x 8 bytes into the LDS image
+  auto transform_store = [&](int s, float* Vb) {
+    if (BNRELU) {
+      const f32x2 sc = *reinterpret_cast<const f32x2*>(p.a_scale + s * 16 + cp * 2), sh = *reinterpret_cast<const f32x2*>(p.a_shift + s * 16 + cp * 2);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const bool ok = voff[q] != WOOB;
+        const float a = fmaxf(fmaf(raw[q].x, sc.x, sh.x), 0.f), b = fmaxf(fmaf(raw[q].y, sc.y, sh.y), 0.f);
+        raw[q] = f32x2{ok ? a : 0.f, ok ? b : 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                 // B^T d: columns
+      const f32x2 d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
+      raw[j] = d0 - d2; raw[4 + j] = d1 + d2; raw[8 + j] = d2 - d1; raw[12 + j] = d1 - d3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                 // (.) B: rows
+      const f32x2 t0 = raw[4 * i], t1 = raw[4 * i + 1], t2 = raw[4 * i + 2], t3 = raw[4 * i + 3];
+      raw[4 * i] = t0 - t2; raw[4 * i + 1] = t1 + t2; raw[4 * i + 2] = t2 - t1; raw[4 * i + 3] = t1 - t3;
+    }
+    const int slot = vslot_base ^ swz(vrow);
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2*>(Vb + ((pos * TT + vrow) * 16 + slot * 4 + vhalf * 2)) = raw[pos];
+  };
+
+  // ---- MFMA role: wave -> positions 2*wave, 2*wave + 1 ----
+  const int pos0 = wave * 2;
+  const f32x4* Uf = reinterpret_cast<const f32x4*>(p.U) + lane;
+  auto load_b = [&](int s, int pos, f32x4 (&b)[3]) {
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) b[nt] = Uf[(((long)s * 16 + pos) * 3 + nt) * 64];
+  };
+  const int aslot = (g ^ swz(l16)) * 4;
+  auto load_a = [&](const float* Vb, int pos, f32x4 (&a)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(Vb + ((pos * TT + mt * 16 + l16) * 16 + aslot));
+  };
+  f32x4 acc[2][4][3];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc[pp][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](f32x4 (&acc1)[4][3], const f32x4 (&a)[4], const f32x4 (&b)[3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[nt][e], acc1[mt][nt], 0, 0, 0);
+  };
+
+  if (s_begin < s_end) {
+    f32x4 b0[3], b1[3], a[4];
+    load_raw(s_begin);
+    load_b(s_begin, pos0, b0);
+    transform_store(s_begin, smem);
+    if (s_begin + 1 < s_end) load_raw(s_begin + 1);
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+      const int buf = (s - s_begin) & 1;
+      const float* Vb = smem + buf * (16 * TT * 16);
+      const bool more = s + 1 < s_end;
+      load_b(s, pos0 + 1, b1);
+      load_a(Vb, pos0, a);
+      mma(acc[0], a, b0);
+      if (more) load_b(s + 1, pos0, b0);
+      load_a(Vb, pos0 + 1, a);
+      mma(acc[1], a, b1);
+      if (more) {
+        transform_store(s + 1, smem + (buf ^ 1) * (16 * TT * 16));     // raw(s+1) has been in flight since the end of the previous iteration
+        if (s + 2 < s_end) load_raw(s + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: M (16 positions) -> LDS, two halves of 32 tiles; Y = A^T M A; store ----
+  float* Ms = smem;
+  const long Mtot = (long)p.B * p.H * p.W;
+  float* dst = p.split > 1 ? p.out + (long)blockIdx.y * Mtot * 48 : p.out;
+  const int ldo = p.split > 1 ? 48 : p.ldc;
+  const int tpi = p.TH * p.TW;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Ms[((pos0 + pp) * 32 + mtl * 16 + 4 * g + r) * LDM + nt * 16 + l16] = h == 0 ? acc[pp][mtl][nt][r] : acc[pp][2 + mtl][nt][r];
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+      const int idx = tid + it * 512;
+      const int tl2 = idx / 48, n = idx - tl2 * 48;
+      const int t = tile0 + h * 32 + tl2;
+      if (t < p.T && n < p.N) {
+        float m[16];
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) m[pos] = Ms[(pos * 32 + tl2) * LDM + n];
+        float u[2][4];                                              // A^T M: rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { u[0][j] = m[j] + m[4 + j] + m[8 + j]; u[1][j] = m[4 + j] - m[8 + j] - m[12 + j]; }
+        const int b = t / tpi, rem = t - b * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const float y0 = u[a2][0] + u[a2][1] + u[a2][2], y1 = u[a2][1] - u[a2][2] - u[a2][3];
+          const int y = 2 * ty + a2, x = 2 * tx;
+          if (y < p.H) {
+            float* o = dst + ((long)(b * p.H + y) * p.W + x) * ldo + n;
+            o[0] = y0;
+            if (x + 1 < p.W) o[ldo] = y1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ordered sum of the split partials [split][M][48] -> out (pixel stride ldc), optional per-channel statistics of the sum
+__global__ __launch_bounds__(256) void k_wino_reduce(const float* __restrict__ part, int split, long M, int N, float* __restrict__ out, int ldc,
+                                                     double* stat0, double* stat1, int rows_per_block) {
+  const int n4 = threadIdx.x % 12, rl = threadIdx.x / 12;          // 12 float4 columns x 21 row lanes (252 of 256 threads)
+  const long m0 = (long)blockIdx.x * rows_per_block;
+  const long m1 = min(M, m0 + rows_per_block);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (rl < 21)
+    for (long m = m0 + rl; m < m1; m += 21) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(part + m * 48 + n4 * 4);
+      for (int s = 1; s < split; ++s) v += *reinterpret_cast<const f32x4*>(part + ((long)s * M + m) * 48 + n4 * 4);
+      float* o = out + m * ldc + n4 * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n4 * 4 + e < N) o[e] = v[e];
+      s0 += v; s1 += v * v;
+    }
+  if (stat0 == nullptr) return;
+  // block reduction: 21 row lanes -> 1
+  __shared__ float red0[21][48], red1[21][48];
+  if (rl < 21) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red0[rl][n4 * 4 + e] = s0[e]; red1[rl][n4 * 4 + e] = s1[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 48 && (int)threadIdx.x < N) {
+    double a = 0, b = 0;
+    for (int r = 0; r < 21; ++r) { a += red0[r][threadIdx.x]; b += red1[r][threadIdx.x]; }
+    atomicAdd(stat0 + threadIdx.x, a);
+    atomicAdd(stat1 + threadIdx.x, b);
+  }
+}
+
+}  // namespace
+
+size_t wino_fwd_workspace_bytes(int C, long M, int split) {
+  const size_t u = (size_t)16 * 48 * C * sizeof(float);
+  const size_t part = split > 1 ? (size_t)split * M * 48 * sizeof(float) : 0;
+  return ((u + 255) & ~(size_t)255) + ((part + 255) & ~(size_t)255);
+}
+
+int wino_pick_split(int T, int nslab) {
+  // one workgroup per CU (128 KB of LDS): the grid runs in ceil(blocks / 256) rounds.  Every split pays ~1.2 slab-times of prologue and
+  // epilogue; pick the split with the smallest (rounds x (slabs per split + 1.2)).
+  const long tb = (T + TT - 1) / TT;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 32 && sp <= nslab / 4 + 1; ++sp) {
+    const long rounds = (tb * sp + 255) / 256;
+    const double cost = rounds * ((nslab + sp - 1) / sp + 1.2);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+
+int launch_wino_weight(const float* w, long wtap, int ldw, int N, int C, float* U, hipStream_t s) {
+  RDM_CHECK_ARG(C % 16 == 0 && N >= 1 && N <= 48, "winograd weights: C (%d) must be a multiple of 16 and N (%d) <= 48", C, N);
+  const long threads = (long)(C / 16) * 3 * 64;
+  hipLaunchKernelGGL(k_wino_weight, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, wtap, ldw, N, C, U);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
+  RDM_CHECK_ARG(a.C % 16 == 0 && a.C > 0 && a.N >= 1 && a.N <= 48, "winograd 3x3: C (%d) must be a multiple of 16, N (%d) <= 48", a.C, a.N);
+  RDM_CHECK_ARG(a.lda % 2 == 0 && ((uintptr_t)a.A & 7) == 0, "winograd 3x3: input stride must be even and the tensor 8-byte aligned");
+  RDM_CHECK_ARG(a.H >= 1 && a.W >= 1 && a.B >= 1, "winograd 3x3: empty geometry");
+  const long M = (long)a.B * a.H * a.W;
+  const long ab = ((M - 1) * a.lda + a.C) * 4;
+  if (ab >= 0xFFFFFFFFL) { set_error("winograd 3x3: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  const int TH = (a.H + 1) / 2, TW = (a.W + 1) / 2;
+  const int T = a.B * TH * TW, nslab = a.C / 16;
+  int split = a.split > 0 ? std::min(a.split, nslab) : wino_pick_split(T, nslab);
+  if (split > 1 && a.partial == nullptr) split = 1;
+  if (split > 1 && a.partial_floats < (size_t)split * M * 48) split = std::max<long>(1, (long)(a.partial_floats / ((size_t)M * 48)));
+  WinoFwdArgs k{};
+  k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.U = a.U;
+  k.out = split > 1 ? a.partial : a.out; k.ldc = a.ldc; k.N = a.N;
+  k.B = a.B; k.H = a.H; k.W = a.W; k.TH = TH; k.TW = TW; k.T = T; k.split = split; k.a_bytes = (unsigned)ab;
+  void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 2);
+  RDM_CENSUS("conv3x3_wino_fwd_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", split > 1 ? "PARTIAL" : (a.stat0 ? "STORE+stats" : "STORE"));
+  dim3 grid((unsigned)cdiv(T, TT), (unsigned)split);
+  if (a.a_scale) hipLaunchKernelGGL(conv3x3_wino_fwd_kernel<true>, grid, dim3(512), 0, s, k);
+  else hipLaunchKernelGGL(conv3x3_wino_fwd_kernel<false>, grid, dim3(512), 0, s, k);
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  if (split > 1 || a.stat0) {
+    // split > 1: ordered sum of the partials into the output slice (+ statistics); split == 1 with statistics: one pass over the slice
+    const float* src = split > 1 ? a.partial : nullptr;
+    if (split > 1) {
+      const int rpb = 84;                                     // 21 row lanes x 4 rows
+      hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, s, src, split, M, a.N, a.out, a.ldc, a.stat0, a.stat1, rpb);
+      RDM_LAUNCH_OK();
+    } else if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
+  }
+  return 0;
+}
+
+}  // namespace rdm

@@ -334,7 +334,7 @@ def test_conv1x1_big_grid_dgrad_and_small_grid_split(cin):
     from md_rdm_amd._lib import ConvDesc, check, ptr, stream
     L = _lib.lib()
     dev = torch.device("cuda:0")
-    B, H, W, cb = 11, 57, 57, 2736
+    B, H, W, cb = (16, 57, 76, 2736) if cin == 96 else (11, 57, 57, 2736)    # N = 96 takes the 128 x 96 tiles only at the headline's 69 312 pixels (>= 512 tiles)
     M, ld = B * H * W, cin + 96
     g = torch.Generator().manual_seed(31 + cin)
     dz = torch.randn(M, cb, generator=g)
@@ -368,10 +368,10 @@ def test_conv1x1_big_grid_dgrad_and_small_grid_split(cin):
     shs = torch.randn(K, generator=g) * 0.3
     wants = torch.relu(xs * scs + shs).double() @ ws.double().t()
     ds = ConvDesc(Bs, Hs, Ws, K, K, N, N, 1, 1, 1, 1, 0, 0)
+    xsg, wsg, scsg, shsg = xs.to(dev), ws.to(dev).view(1, N, K).contiguous(), scs.to(dev), shs.to(dev)
     for split in (1, 4, 0):
         y = torch.full((Ms, N), float("nan"), device=dev)
-        check(L.rdm_conv2d_fwd_ex(C.byref(ds), ptr(xs.to(dev)), ptr(ws.to(dev).view(1, N, K).contiguous()), None, ptr(scs.to(dev)), ptr(shs.to(dev)),
-                                  ptr(y), None, None, split, stream()))
+        check(L.rdm_conv2d_fwd_ex(C.byref(ds), ptr(xsg), ptr(wsg), None, ptr(scsg), ptr(shsg), ptr(y), None, None, split, stream()))
         assert rel(y.cpu().double(), wants) < TOL, split
     cen = _lib.census()
     assert cen.get("conv_fwd_kernel/fwd/1x1/tile128x48/ATOMIC", 0) >= 1 and cen.get("conv_fwd_kernel/fwd/1x1/tile128x48/STORE", 0) >= 1
