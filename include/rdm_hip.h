@@ -48,8 +48,8 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..8 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the f32 MFMA kernels,
- * 7-8 the bf16 forward kernels), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..10 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
+ * 7-8 the bf16 forward kernels, 9-10 the Winograd f32 kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for kinds 0-6) */
 double rdm_profile_kind_bytes(int32_t kind);
@@ -237,8 +237,11 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                flat parameter buffer and exposes OIHW-shaped strided views): removes 78 pack launches per forward
  *                                and 78 unpack launches + 78 scratch fills per backward.
  *   RDM_NET_OPT_GRADS_PREZEROED  the caller guarantees that every gradient tensor is all zero when backward stage 0 starts (one fill
- *                                of a flat gradient buffer instead of ~160 per-tensor fills inside the plan). */
-typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2 } rdm_net_option;
+ *                                of a flat gradient buffer instead of ~160 per-tensor fills inside the plan).
+ *   RDM_NET_OPT_DIRECT_3X3       every 3x3 convolution on the direct implicit-GEMM kernels (default 0: the blocks with >= 16 384 pixels -
+ *                                dense_e2 / dense_e3 at the headline geometry - run Winograd F(2x2, 3x3), csrc/wino.hip; same result to
+ *                                float32 rounding, tests/test_gpu_wino.py). */
+typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -11,6 +11,11 @@ LIB = os.path.join(HERE, "librdm_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
+# per-file extra flags.  wino.hip: the SLP vectoriser turns the in-register Winograd transforms into v_pk_add_f32, which issue slower
+# than two v_add_f32 beside MFMAs (MI355X_MICROARCH.md, cycle constants: "packed f32 VALU ... an anti-lever beside MFMAs")
+EXTRA = {"wino.hip": ["-fno-slp-vectorize"] if os.environ.get("RDM_WINO_SLP", "0") in ("", "0") else []}
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -41,7 +46,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -18,6 +18,7 @@
 #include "rdm_common.h"
 #include "elementwise.h"
 #include "bf16.h"
+#include "wino.h"
 
 namespace rdm {
 
@@ -171,8 +172,15 @@ struct NetImpl {
   ~NetImpl() {
     if (side) { hipStreamDestroy(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
   }
+  // Winograd F(2x2, 3x3) for the 3x3 convs of the blocks with many pixels (wino.hip): transformed weights per layer (formed on the side
+  // stream at the start of forward) and one scratch for the per-split partial outputs
+  bool wino_fwd[4] = {false, false, false, false};
+  int wino_split[4] = {1, 1, 1, 1};
+  size_t winoPartial = 0, winoPartialFloats = 0;
+  std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
+  int opt_no_wino = 0;         // RDM_NET_OPT_DIRECT_3X3: keep the direct implicit-GEMM kernels everywhere (A/B and tests)
   int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
   int opt_prezeroed = 0;       // RDM_NET_OPT_GRADS_PREZEROED: every gradient tensor is zero when backward stage 0 starts
   // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
@@ -268,6 +276,18 @@ struct NetImpl {
     }
     logits = a.take<float>((size_t)bg[3].M * 192);
     w2pad = a.take<float>((size_t)192 * 2208);
+    for (int b = 0; b < 4; ++b) {
+      // Winograd where the 2.25x fewer MFMAs outweigh the transforms: >= 16 K pixels (dense_e2 / dense_e3 at the headline geometry;
+      // measured at 4 560 pixels it loses to the direct kernel, 0.052 vs 0.045 ms)
+      wino_fwd[b] = bg[b].M >= 16384 && bg[b].cb % 16 == 0;
+      if (!wino_fwd[b]) continue;
+      const int T = B * ((bg[b].H + 1) / 2) * ((bg[b].W + 1) / 2);
+      wino_split[b] = wino_pick_split(T, bg[b].cb / 16);
+      if (wino_split[b] > 1) winoPartialFloats = std::max(winoPartialFloats, (size_t)wino_split[b] * bg[b].M * 48);
+      winoU[b].resize(kBlocks[b].layers);
+      for (auto& o : winoU[b]) o = a.take<float>((size_t)16 * 48 * bg[b].cb);
+    }
+    winoPartial = a.take<float>(winoPartialFloats);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
     for (int b = 0; b < 4; ++b) {
@@ -406,9 +426,19 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     c.Wt = w2p; c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
     c.out = blk + cin; c.ldc = g.ctot; c.M = g.M; c.N = GROWTH;
     c.stat0 = bst + cin; c.stat1 = bst + g.ctot + cin;
-    const bool fuse2 = training && fuse_stats(g.M, GROWTH);
-    if ((rc = launch_conv_fwd(c, false, fuse2 ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
-    if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
+    if (n.wino_fwd[b] && !n.opt_no_wino) {
+      // Winograd F(2x2, 3x3): the ordered reduction of the split partials also takes the channel statistics (no zero fill, no separate pass)
+      WinoConv wv{};
+      wv.A = Y; wv.lda = g.cb; wv.C = g.cb; wv.a_scale = bn2; wv.a_shift = bn2 + g.cb; wv.U = at<float>(ws, n.winoU[b][i]);
+      wv.out = blk + cin; wv.ldc = g.ctot; wv.N = GROWTH; wv.B = n.B; wv.H = g.H; wv.W = g.W;
+      wv.split = n.wino_split[b]; wv.partial = at<float>(ws, n.winoPartial); wv.partial_floats = n.winoPartialFloats;
+      if (training) { wv.stat0 = bst + cin; wv.stat1 = bst + g.ctot + cin; }
+      if ((rc = launch_conv3x3_wino_fwd(wv, s))) return rc;
+    } else {
+      const bool fuse2 = training && fuse_stats(g.M, GROWTH);
+      if ((rc = launch_conv_fwd(c, false, fuse2 ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
+      if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
+    }
     if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[i & 1], s));     // layer i's output channels + their statistics are final
   }
   return 0;
@@ -612,6 +642,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   NetImpl* n = reinterpret_cast<NetImpl*>(net);
   if (option == RDM_NET_OPT_PACKED_3X3) n->opt_packed3x3 = value != 0;
   else if (option == RDM_NET_OPT_GRADS_PREZEROED) n->opt_prezeroed = value != 0;
+  else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }
@@ -694,6 +725,12 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
     for (int b = 0; b < 4; ++b)
       for (int i = 0; i < kBlocks[b].layers; ++i)
         if ((rc = launch_pack_w(F(T, reg().layers[b][i].conv2), at<float>(ws, n.lws[b][i].w2p), GROWTH, n.bg[b].cb, 9, GROWTH, n.side))) return rc;
+  for (int b = 0; b < 4; ++b)                                 // Winograd weight transforms U = G g G^T, off the critical path like the packing
+    if (n.wino_fwd[b] && !n.opt_no_wino)
+      for (int i = 0; i < kBlocks[b].layers; ++i) {
+        const float* w2p = n.opt_packed3x3 ? F(T, reg().layers[b][i].conv2) : at<float>(ws, n.lws[b][i].w2p);
+        if ((rc = launch_wino_weight(w2p, (long)GROWTH * n.bg[b].cb, n.bg[b].cb, GROWTH, n.bg[b].cb, at<float>(ws, n.winoU[b][i]), n.side))) return rc;
+      }
   RDM_HIP_OK(hipEventRecord(n.ev_side, n.side));
   // stem: 7x7/s2 conv as im2col + GEMM (K = 147 padded to 160), bias, then 3x3/s2 max-pool
   if ((rc = launch_im2col_stem(x, at<float>(ws, n.patches), n.B, n.H0, n.W0, s))) return rc;

@@ -10,19 +10,20 @@
 //
 // MI355X mapping (not a cuDNN translation):
 //  * the 16 transform positions are 16 INDEPENDENT GEMMs  M_pos[tile][n] = sum_c V_pos[tile][c] * U_pos[n][c]; a 512-thread workgroup
-//    (8 wave64s, one per CU: two per SIMD) owns 64 tiles (256 output pixels) x 48 channels, wave w owns positions 2w, 2w+1: 2 x (4 x 3)
-//    MFMA tiles = 96 accumulator registers, and no two waves ever need the same operand fragment.
+//    (8 wave64s, one per CU: two per SIMD) owns 64 tiles (256 output pixels) x 48 channels; four CONSUMER waves own 4 positions each
+//    (4 x (4 x 3) MFMA tiles = 192 accumulator registers; no two waves ever need the same operand fragment), four PRODUCER waves form V.
 //  * U (the transformed weights) never touches LDS: it is stored in HBM in FRAGMENT order [slab][pos][n-tile][lane][4] by a tiny
 //    transform kernel, so a wave's B fragment is one fully coalesced 1-KiB global_load_dwordx4 (L2 resident: 48 KB per slab, shared
 //    by every workgroup).
-//  * V (the transformed activations) is formed in registers: thread (tile, channel pair) gathers its 4x4 patch with 16 buffer loads
+//  * V (the transformed activations) is formed in registers: a producer thread (tile, channel quad) gathers its 4x4 patch with 16 buffer loads
 //    (hardware range check = zero padding outside the tensor), applies the consumer BatchNorm + ReLU, masks the zero-padded positions,
-//    runs the two 1-D transforms in place (64 adds) and writes 16 x 8 bytes into a double-buffered, chunk-swizzled LDS image
+//    runs the two 1-D transforms in place (32 adds per channel) and writes 16 x 16 bytes into a double-buffered, chunk-swizzled LDS image
 //    [pos][tile][16 k]: ONE barrier per 16-channel slab.  A fragments are conflict-free ds_read_b128 (4 consecutive k per lane; the
 //    k permutation is shared with the B fragments).
 //  * split-K writes per-split partial OUTPUTS (the output transform is linear) with plain stores; a small ordered reduction adds them
 //    in a fixed order and takes the per-channel statistics of the sum - deterministic, and 5x the byte rate of f32 atomics.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "rdm_common.h"
 #include "elementwise.h"
@@ -33,6 +34,7 @@ namespace rdm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -100,7 +102,15 @@ struct WinoFwdArgs {
   unsigned a_bytes;
 };
 
-template <bool BNRELU>
+// Wave specialisation: waves 0-3 are CONSUMERS (one per SIMD; wave w owns transform positions 4w .. 4w+3: 4 x (4 x 3) MFMA tiles = 192
+// accumulator registers, 192 MFMAs per 16-channel slab = the SIMD's matrix pipe for 6 144 cycles, next to 16 ds_read_b128 and 12 coalesced
+// 1-KiB weight-fragment loads), waves 4-7 are PRODUCERS (the partner wave on each SIMD: gather, BatchNorm + ReLU, transforms, LDS stores
+// for slab s+1 while slab s is being multiplied).  The two streams meet at ONE workgroup barrier per slab; the producers' gathers for
+// slab s+2 are issued before it and have a whole slab time to land.  (A first version in which all 8 waves did both jobs in lockstep
+// ran at 54 % of the matrix pipe: both waves of a SIMD stalled on the same loads at the same time.)
+// ABL: timing-only ablations for tools/wino_bench.py (RDM_DEV_VARIANTS builds; results are wrong): 1 no gathers after the prologue,
+// 2 no weight-fragment loads in the loop, 4 no MFMAs, 8 no producer arithmetic (BatchNorm, transforms)
+template <bool BNRELU, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_fwd_kernel(WinoFwdArgs p) {
   __shared__ __attribute__((aligned(1024))) float smem[2 * 16 * TT * 16];        // V double buffer: 2 x 64 KB; reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,116 +123,145 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_fwd_kernel(WinoFwdArgs p)
     s_end = min(nslab, s_begin + per);
   }
   const int tile0 = blockIdx.x * TT;
-
-  // ---- staging role: thread -> (tile tl, channel pair cp) ----
-  const int tl = tid >> 3, cp = tid & 7;
-  unsigned voff[16];
-  {
-    const int t = tile0 + tl;
-    const bool tok = t < p.T;
-    const int tpi = p.TH * p.TW;
-    const int b = t / tpi, rem = t - b * tpi;
-    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+  const bool producer = wave >= 4;
+  const int pos0 = (wave & 3) * 4;
+  f32x4 acc[4][4][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
-        const bool ok = tok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        voff[i * 4 + j] = ok ? (unsigned)((b * p.H + y) * p.W + x) * (unsigned)(p.lda * 4) + (unsigned)(cp * 8) : WOOB;
-      }
-  }
-  const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
-  const int vrow = tl, vslot_base = cp >> 1, vhalf = cp & 1;
-  f32x2 raw[16];
-  auto load_raw = [&](int s) {
-    const unsigned so = (unsigned)(s * 64);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(srdA, (int)(voff[q] == WOOB ? WOOB : voff[q] + so), 0, 0);
-      raw[q] = f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
-    }
-  };
-  // BatchNorm + ReLU of the consumer, zero for the padded positions, then V = B^T d B in place, then 16 x 8 bytes into the LDS image
-  auto transform_store = [&](int s, float* Vb) {
-    if (BNRELU) {
-      const f32x2 sc = *reinterpret_cast<const f32x2*>(p.a_scale + s * 16 + cp * 2), sh = *reinterpret_cast<const f32x2*>(p.a_shift + s * 16 + cp * 2);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const bool ok = voff[q] != WOOB;
-        const float a = fmaxf(fmaf(raw[q].x, sc.x, sh.x), 0.f), b = fmaxf(fmaf(raw[q].y, sc.y, sh.y), 0.f);
-        raw[q] = f32x2{ok ? a : 0.f, ok ? b : 0.f};
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                                 // B^T d: columns
-      const f32x2 d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
-      raw[j] = d0 - d2; raw[4 + j] = d1 + d2; raw[8 + j] = d2 - d1; raw[12 + j] = d1 - d3;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                                 // (.) B: rows
-      const f32x2 t0 = raw[4 * i], t1 = raw[4 * i + 1], t2 = raw[4 * i + 2], t3 = raw[4 * i + 3];
-      raw[4 * i] = t0 - t2; raw[4 * i + 1] = t1 + t2; raw[4 * i + 2] = t2 - t1; raw[4 * i + 3] = t1 - t3;
-    }
-    const int slot = vslot_base ^ swz(vrow);
-#pragma unroll
-    for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2*>(Vb + ((pos * TT + vrow) * 16 + slot * 4 + vhalf * 2)) = raw[pos];
-  };
-
-  // ---- MFMA role: wave -> positions 2*wave, 2*wave + 1 ----
-  const int pos0 = wave * 2;
-  const f32x4* Uf = reinterpret_cast<const f32x4*>(p.U) + lane;
-  auto load_b = [&](int s, int pos, f32x4 (&b)[3]) {
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = Uf[(((long)s * 16 + pos) * 3 + nt) * 64];
-  };
-  const int aslot = (g ^ swz(l16)) * 4;
-  auto load_a = [&](const float* Vb, int pos, f32x4 (&a)[4]) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(Vb + ((pos * TT + mt * 16 + l16) * 16 + aslot));
-  };
-  f32x4 acc[2][4][3];
-#pragma unroll
-  for (int pp = 0; pp < 2; ++pp)
+  for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) acc[pp][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma = [&](f32x4 (&acc1)[4][3], const f32x4 (&a)[4], const f32x4 (&b)[3]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[nt][e], acc1[mt][nt], 0, 0, 0);
-  };
 
   if (s_begin < s_end) {
-    f32x4 b0[3], b1[3], a[4];
-    load_raw(s_begin);
-    load_b(s_begin, pos0, b0);
-    transform_store(s_begin, smem);
-    if (s_begin + 1 < s_end) load_raw(s_begin + 1);
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-      const int buf = (s - s_begin) & 1;
-      const float* Vb = smem + buf * (16 * TT * 16);
-      const bool more = s + 1 < s_end;
-      load_b(s, pos0 + 1, b1);
-      load_a(Vb, pos0, a);
-      mma(acc[0], a, b0);
-      if (more) load_b(s + 1, pos0, b0);
-      load_a(Vb, pos0 + 1, a);
-      mma(acc[1], a, b1);
-      if (more) {
-        transform_store(s + 1, smem + (buf ^ 1) * (16 * TT * 16));     // raw(s+1) has been in flight since the end of the previous iteration
-        if (s + 2 < s_end) load_raw(s + 2);
+    if (producer) {
+      // ---- producer: thread -> channel quad cq (4 consecutive channels = one 16-byte chunk of the slab) of tile tl ----
+      // Everything here competes with the partner wave's MFMAs for the SIMD's issue port (measured: the producers' vector instructions
+      // ADD to the slab time, they do not hide under the matrix pipe), so the instruction count is what is minimised: one 16-byte
+      // gather per patch position, BatchNorm + ReLU + zero padding in two instructions per element (v_fma, v_med3 against a per-position
+      // upper bound that is +inf inside the image and 0 in the padding), the two 1-D transforms in place, one 16-byte LDS store per position.
+      const int ptid = tid - 256, tl = ptid >> 2, cq = ptid & 3;
+      unsigned voff[16];
+      float hi[16];
+      {
+        const int t = tile0 + tl;
+        const bool tok = t < p.T;
+        const int tpi = p.TH * p.TW;
+        const int b = t / tpi, rem = t - b * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+            const bool ok = tok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i * 4 + j] = ok ? (unsigned)((b * p.H + y) * p.W + x) * (unsigned)(p.lda * 4) + (unsigned)(cq * 16) : WOOB;
+            hi[i * 4 + j] = ok ? __builtin_inff() : 0.f;
+          }
       }
-      __syncthreads();
+      const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
+      const int slot = cq ^ swz(tl);
+      float rv[4][16];                               // [channel][patch position]; scalar arrays (a vector type would make the transforms
+                                                     // v_pk_add_f32, which issues slower beside the partner wave's MFMAs than two v_add_f32)
+      auto load_raw = [&](int s) {
+        // the slab's channel offset travels in the scalar offset: the range check looks at the vector offset alone, where WOOB marks
+        // a padded position (a valid offset + s*64 stays inside the tensor: s*16 + 4*cq + 3 < C)
+        const int so = s * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srdA, (int)voff[q], so, 0);
+          rv[0][q] = __uint_as_float(v.x); rv[1][q] = __uint_as_float(v.y); rv[2][q] = __uint_as_float(v.z); rv[3][q] = __uint_as_float(v.w);
+        }
+      };
+      auto transform_store = [&](int s, float* Vb) {
+        if (BNRELU && !(ABL & 8)) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.a_scale + s * 16 + cq * 4), sh = *reinterpret_cast<const f32x4*>(p.a_shift + s * 16 + cq * 4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rv[c][q] = __builtin_amdgcn_fmed3f(fmaf(rv[c][q], sc[c], sh[c]), 0.f, hi[q]);
+        }
+#define RDM_WINO_1D(v, i0, i1, i2, i3)                                                        \
+        { const float d0 = v[i0], d1 = v[i1], d2 = v[i2], d3 = v[i3];                         \
+          v[i0] = d0 - d2; v[i1] = d1 + d2; v[i2] = d2 - d1; v[i3] = d1 - d3; }
+        if (!(ABL & 8)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) RDM_WINO_1D(rv[c], j, 4 + j, 8 + j, 12 + j)                      // B^T d: columns
+#pragma unroll
+            for (int i = 0; i < 4; ++i) RDM_WINO_1D(rv[c], 4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3)      // (.) B: rows
+          }
+        }
+#undef RDM_WINO_1D
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+          *reinterpret_cast<f32x4*>(Vb + ((pos * TT + tl) * 16 + slot * 4)) = f32x4{rv[0][pos], rv[1][pos], rv[2][pos], rv[3][pos]};
+      };
+      load_raw(s_begin);
+      transform_store(s_begin, smem);
+      load_raw(min(s_begin + 1, s_end - 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) {
+          transform_store(s + 1, smem + (buf ^ 1) * (16 * TT * 16));      // raw(s+1) has been in flight for a whole slab time
+          if (!(ABL & 1)) load_raw(min(s + 2, s_end - 1));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the LDS stores have landed before the barrier releases the readers
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // ---- consumer: positions pos0 .. pos0 + 3 ----
+      const f32x4* Uf = reinterpret_cast<const f32x4*>(p.U) + lane;
+      auto load_b = [&](int s, int pos, f32x4 (&b)[3]) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[nt] = Uf[(((long)s * 16 + pos) * 3 + nt) * 64];
+      };
+      const int aslot = (g ^ swz(l16)) * 4;
+      // Software pipeline, pinned with sched_barrier (left alone, hipcc sinks every load next to its first use and the matrix pipe waits
+      // for L2): the B fragments of position pp+1 (three 1-KiB loads) are issued before the 48 MFMAs of position pp, the A fragment of
+      // M-tile mt+1 (one ds_read_b128) before the 12 MFMAs of M-tile mt.  MFMA order mt -> e -> nt: an accumulator is revisited after 3
+      // MFMAs (96 cycles > the 40-cycle dependent latency).
+      f32x4 bq[2][3], aq[2];
+      auto load_a1 = [&](const float* Vb, int pos, int mt) { return *reinterpret_cast<const f32x4*>(Vb + ((pos * TT + mt * 16 + l16) * 16 + aslot)); };
+      load_b(s_begin, pos0, bq[0]);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int s = s_begin; s < s_end; ++s) {
+        const float* Vb = smem + ((s - s_begin) & 1) * (16 * TT * 16);
+        aq[0] = load_a1(Vb, pos0, 0);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          if (!(ABL & 2)) {
+            if (pp < 3) load_b(s, pos0 + pp + 1, bq[(pp + 1) & 1]);
+            else load_b(min(s + 1, s_end - 1), pos0, bq[0]);
+          } else if (s == s_begin) load_b(s, pos0 + pp, bq[(pp + 1) & 1]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int cur = (pp * 4 + mt) & 1;
+            if (mt < 3) aq[cur ^ 1] = load_a1(Vb, pos0 + pp, mt + 1);
+            else if (pp < 3) aq[cur ^ 1] = load_a1(Vb, pos0 + pp + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int nt = 0; nt < 3; ++nt)
+                if (!(ABL & 4)) acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][e], bq[pp & 1][nt][e], acc[pp][mt][nt], 0, 0, 0);
+                else asm volatile("" :: "v"(aq[cur][e]), "v"(bq[pp & 1][nt][e]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
     }
   }
+  __syncthreads();
 
-  // ---- epilogue: M (16 positions) -> LDS, two halves of 32 tiles; Y = A^T M A; store ----
+  // ---- epilogue: M (16 positions, held by the consumers) -> LDS, two halves of 32 tiles; Y = A^T M A; store ----
   float* Ms = smem;
   const long Mtot = (long)p.B * p.H * p.W;
   float* dst = p.split > 1 ? p.out + (long)blockIdx.y * Mtot * 48 : p.out;
@@ -230,15 +269,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_fwd_kernel(WinoFwdArgs p)
   const int tpi = p.TH * p.TW;
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
+    if (!producer) {
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+      for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-      for (int mtl = 0; mtl < 2; ++mtl)
+        for (int mtl = 0; mtl < 2; ++mtl)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
+          for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            Ms[((pos0 + pp) * 32 + mtl * 16 + 4 * g + r) * LDM + nt * 16 + l16] = h == 0 ? acc[pp][mtl][nt][r] : acc[pp][2 + mtl][nt][r];
+            for (int r = 0; r < 4; ++r)
+              Ms[((pos0 + pp) * 32 + mtl * 16 + 4 * g + r) * LDM + nt * 16 + l16] = h == 0 ? acc[pp][mtl][nt][r] : acc[pp][2 + mtl][nt][r];
+    }
     __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < 3; ++it) {
@@ -335,7 +376,7 @@ int launch_wino_weight(const float* w, long wtap, int ldw, int N, int C, float* 
 
 int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
   RDM_CHECK_ARG(a.C % 16 == 0 && a.C > 0 && a.N >= 1 && a.N <= 48, "winograd 3x3: C (%d) must be a multiple of 16, N (%d) <= 48", a.C, a.N);
-  RDM_CHECK_ARG(a.lda % 2 == 0 && ((uintptr_t)a.A & 7) == 0, "winograd 3x3: input stride must be even and the tensor 8-byte aligned");
+  RDM_CHECK_ARG(a.lda % 4 == 0 && ((uintptr_t)a.A & 15) == 0, "winograd 3x3: input stride must be a multiple of 4 floats and the tensor 16-byte aligned");
   RDM_CHECK_ARG(a.H >= 1 && a.W >= 1 && a.B >= 1, "winograd 3x3: empty geometry");
   const long M = (long)a.B * a.H * a.W;
   const long ab = ((M - 1) * a.lda + a.C) * 4;
@@ -349,11 +390,18 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
   k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.U = a.U;
   k.out = split > 1 ? a.partial : a.out; k.ldc = a.ldc; k.N = a.N;
   k.B = a.B; k.H = a.H; k.W = a.W; k.TH = TH; k.TW = TW; k.T = T; k.split = split; k.a_bytes = (unsigned)ab;
-  void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 2);
+  void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 9);
   RDM_CENSUS("conv3x3_wino_fwd_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", split > 1 ? "PARTIAL" : (a.stat0 ? "STORE+stats" : "STORE"));
   dim3 grid((unsigned)cdiv(T, TT), (unsigned)split);
-  if (a.a_scale) hipLaunchKernelGGL(conv3x3_wino_fwd_kernel<true>, grid, dim3(512), 0, s, k);
-  else hipLaunchKernelGGL(conv3x3_wino_fwd_kernel<false>, grid, dim3(512), 0, s, k);
+#ifdef RDM_DEV_VARIANTS
+  const char* abl_env = getenv("RDM_WINO_ABL");
+  const int abl = abl_env ? atoi(abl_env) : 0;
+#define RDM_ABL(N_) if (abl == N_) hipLaunchKernelGGL((conv3x3_wino_fwd_kernel<true, N_>), grid, dim3(512), 0, s, k); else
+  RDM_ABL(1) RDM_ABL(2) RDM_ABL(3) RDM_ABL(4) RDM_ABL(8) RDM_ABL(9) RDM_ABL(11) RDM_ABL(12) RDM_ABL(13) RDM_ABL(15)
+#undef RDM_ABL
+#endif
+  if (a.a_scale) hipLaunchKernelGGL((conv3x3_wino_fwd_kernel<true>), grid, dim3(512), 0, s, k);
+  else hipLaunchKernelGGL((conv3x3_wino_fwd_kernel<false>), grid, dim3(512), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   if (split > 1 || a.stat0) {

@@ -9,19 +9,16 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
-_RAN = set()          # headline-size parity cases that ran in this process (the census test at the end of the module needs all of them)
+import conftest
+
+_RAN = conftest.RAN.setdefault(__name__, set())          # headline-size parity cases that ran in this process (tests/test_gpu_zz_coverage.py needs all of them)
 
 
 @pytest.fixture(scope="module", autouse=True)
-def _census():
-    """Kernel-variant census for the whole module (rdm_census_*): the last test asserts that every variant the headline geometry
-    selects was launched by one of the oracle comparisons above it."""
-    from md_rdm_amd import _lib
-    L = _lib.lib()
-    L.rdm_census_reset()
-    L.rdm_census_enable(1)
+def _census(op_census):
+    """Kernel-variant census for the whole module (conftest.op_census): tests/test_gpu_zz_coverage.py asserts that every variant the
+    headline geometry selects was launched by one of the oracle comparisons of the operator-level modules."""
     yield
-    L.rdm_census_enable(0)
 
 
 def nhwc(t):
@@ -424,30 +421,3 @@ def test_fused_adamw_matches_torch():
         opt.step()
         check(L.rdm_adamw_fused(ptr(pg), ptr(gr.to(dev)), ptr(m), ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, step, 1.0, stream()))
     assert rel(pg.cpu(), p.detach()) < 1e-6
-
-
-def test_every_headline_kernel_variant_was_launched_by_a_parity_test():
-    """Self-checking coverage.  Run one B=16 228x304 train step (the bench geometry) with the census on and collect the kernel VARIANTS
-    the plan selects; every one of them must already have been launched by an oracle comparison of this module (the census is reset
-    when the module starts and the whole-step launches are counted separately).  Skipped when the module was only run in part."""
-    from md_rdm_amd import _lib, filler, harness
-    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
-    need = len(ROW_WGRAD_CASES) + len(HALO_CASES) + 8 + 2
-    if len(_RAN) < need:
-        pytest.skip(f"only {len(_RAN)} of {need} headline parity cases ran in this process")
-    L = _lib.lib()
-    by_tests = _lib.census()
-    L.rdm_census_reset()
-    dev = torch.device("cuda:0")
-    m = DepthEstimationNet()
-    filler.fill_state_dict(m.state_dict())
-    m = m.to(dev).train()
-    x, y = filler.synthetic_batch(16, 228, 304, seed=1234)
-    loss, _ = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
-    loss.backward()
-    torch.cuda.synchronize()
-    step = _lib.census()
-    assert len(step) >= 10 and any(k.startswith("conv_wgrad3_row_kernel") for k in step) and any("px256" in k for k in step) and any(
-        k.startswith("conv1x1_dma256_kernel") for k in step), sorted(step)
-    missing = sorted(k for k in step if by_tests.get(k, 0) == 0)
-    assert not missing, "kernel variants of the headline step that no parity test launched: %r" % missing

@@ -1,0 +1,85 @@
+"""-m gpu: Winograd F(2x2, 3x3) (csrc/wino.hip) through the C ABI vs a float64 torch-CPU evaluation of the same convolution (shifted-slice
+matmuls: the definition, no library conv) - the SAME 2e-5-of-max tolerance the direct implicit-GEMM kernels are held to."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import conftest
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+_RAN = conftest.RAN.setdefault(__name__, set())
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _census(op_census):
+    yield
+
+
+def rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def ref3x3(a, w9):
+    B, H, W, Cc = a.shape
+    ap = F.pad(a, (0, 0, 1, 1, 1, 1))
+    y = torch.zeros(B * H * W, w9.shape[1], dtype=torch.float64)
+    for r in range(3):
+        for q in range(3):
+            y += ap[:, r:r + H, q:q + W, :].reshape(-1, Cc) @ w9[r * 3 + q].t()
+    return y
+
+
+CASES = [
+    # B, H, W, Cb, ld, N, bn
+    (2, 57, 76, 2736, 2736, 48, True),       # dense_e2's conv2 (RDM_Net.py:526): odd height (a half-valid last tile row)
+    (16, 29, 38, 1392, 1392, 48, True),      # dense_e3's conv2 at the bench batch (RDM_Net.py:528)
+    (3, 8, 10, 384, 400, 48, True),          # decoder-sized map, ld > C with NaN behind the contracted prefix
+    (1, 7, 5, 48, 48, 48, False),            # odd width and height, fewer tiles than one workgroup, no prologue
+    (5, 13, 21, 96, 96, 40, True),           # N < 48
+    (1, 1, 1, 16, 16, 16, True),             # single pixel
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"w{i}" for i in range(len(CASES))])
+def test_wino_forward_vs_float64(case):
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cb, ld, N, bn = case
+    M = B * H * W
+    g = torch.Generator().manual_seed(4000 + Cb + W)
+    y = torch.randn(B, H, W, ld, generator=g)
+    y[..., Cb:] = float("nan")
+    w = torch.randn(9, N, Cb, generator=g) / (9 * Cb) ** 0.5
+    sc = torch.rand(Cb, generator=g) + 0.5
+    sh = torch.randn(Cb, generator=g) * 0.3
+    a = (torch.relu(y[..., :Cb] * sc + sh) if bn else y[..., :Cb]).double()
+    want = ref3x3(a, w.double())
+    d = ConvDesc(B, H, W, Cb, ld, N, 64, 3, 3, 1, 1, 1, 1)               # output into a 64-wide buffer: a channel slice, as in the block buffers
+    yg, wg, scg, shg = y.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    outs = []
+    for split, stats in ((1, False), (0, True), (3, True), (0, False)):
+        nb = int(L.rdm_conv3x3_wino_workspace_bytes(Cb, B, H, W, split))
+        ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+        out = torch.full((M, 64), float("nan"), device=dev)
+        ssum = torch.zeros(N, dtype=torch.float64, device=dev)
+        ssq = torch.zeros_like(ssum)
+        check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out),
+                                     ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), nb, split, stream()))
+        got = out.cpu()
+        assert torch.isnan(got[:, N:]).all()                               # nothing outside the N-channel slice is written
+        assert rel(got[:, :N].double(), want) < TOL, (split, stats)
+        if stats:
+            assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+        outs.append((split, got[:, :N].clone()))
+    # no atomics anywhere: the same split is bit-reproducible
+    nb = int(L.rdm_conv3x3_wino_workspace_bytes(Cb, B, H, W, 3))
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+    out = torch.full((M, 64), float("nan"), device=dev)
+    check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out), None, None, ptr(ws), nb, 3, stream()))
+    assert torch.equal(out.cpu()[:, :N], outs[2][1])
+    _RAN.add(case)
