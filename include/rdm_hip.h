@@ -48,8 +48,8 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..10 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
- * 7-8 the bf16 forward kernels, 9-10 the Winograd f32 kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..9 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
+ * 7-8 the bf16 forward kernels, 9 the Winograd f32 forward kernel - its FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for kinds 0-6) */
 double rdm_profile_kind_bytes(int32_t kind);

@@ -20,6 +20,9 @@
 //    runs the two 1-D transforms in place (32 adds per channel) and writes 16 x 16 bytes into a double-buffered, chunk-swizzled LDS image
 //    [pos][tile][16 k]: ONE barrier per 16-channel slab.  A fragments are conflict-free ds_read_b128 (4 consecutive k per lane; the
 //    k permutation is shared with the B fragments).
+//  * measured and NOT built into the plan: the same transform for the dgrad (K = 48 contracted channels, 57 column blocks of outputs at
+//    dense_e2).  With three K slabs the expanded operands are not amortised - 149 operand bytes per MFMA against the direct halo
+//    kernel's 31 - and the kernel runs at the L2 -> CU feed rate, 1.65 ms against the direct kernel's 1.66 ms (round 3; removed again).
 //  * split-K writes per-split partial OUTPUTS (the output transform is linear) with plain stores; a small ordered reduction adds them
 //    in a fixed order and takes the per-channel statistics of the sum - deterministic, and 5x the byte rate of f32 atomics.
 #include <algorithm>
@@ -53,7 +56,7 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> ((row >> 1) & 6)) 
 
 // ---------------------------------------------------------------------------------------------
 // weight transform  U = G g G^T  ->  fragment order [slab][pos][nt][lane = g*16 + l16][e]:  n = nt*16 + l16, c = slab*16 + 4*g + e
-// (w_packed is [tap = r*3 + q][n][c], `flip` reads tap (2-r)*3 + (2-q): the dgrad correlation)
+// (w_packed is [tap = r*3 + q][n][c])
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w, long wtap, int ldw, int N, int C, float* __restrict__ U) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per (slab, nt, lane): produces 16 positions x 4 e
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(256) void k_wino_reduce(const float* __restrict__ p
     atomicAdd(stat1 + threadIdx.x, b);
   }
 }
+
 
 }  // namespace
 

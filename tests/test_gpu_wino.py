@@ -83,3 +83,4 @@ def test_wino_forward_vs_float64(case):
     check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out), None, None, ptr(ws), nb, 3, stream()))
     assert torch.equal(out.cpu()[:, :N], outs[2][1])
     _RAN.add(case)
+
