@@ -195,7 +195,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
         achieved = algo / (ms.value * 1e-3) / 1e12
         per_kernel = []
-        for kind in range(10):
+        for kind in range(11):
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:

@@ -48,8 +48,8 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..9 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
- * 7-8 the bf16 forward kernels, 9 the Winograd f32 forward kernel - its FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..10 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
+ * 7-8 the bf16 forward kernels, 9-10 the Winograd f32 forward / weight-gradient kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for kinds 0-6) */
 double rdm_profile_kind_bytes(int32_t kind);
@@ -141,6 +141,13 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
 size_t rdm_conv3x3_wino_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k);
 int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
                          double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream);
+
+/* ... and the weight gradient of that convolution as Winograd F(3x3, 2x2): same operands and meaning as rdm_conv2d_wgrad (BatchNorm + ReLU
+ * prologue on x), except that dw_packed [9][out_c][in_c] is WRITTEN, not accumulated, and that the K-split partial sums are combined
+ * in a fixed order (no atomics: bit-reproducible).  The workspace holds the transformed gradient and the per-split partial sums. */
+size_t rdm_conv3x3_wino_wgrad_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w);
+int rdm_conv3x3_wino_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw_packed,
+                           void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 
 /* [out][in][kh][kw] (PyTorch) <-> [tap][out_pad][in] (packed); rows >= out_c are zero-filled. */
 int rdm_pack_conv_weight(const float* w_oihw, float* w_packed, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw,

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "rdm_conv2d_wgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "rdm_conv3x3_wino_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "rdm_conv3x3_wino_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]),
+    "rdm_conv3x3_wino_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "rdm_conv3x3_wino_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
     "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_gemm_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),

@@ -217,6 +217,35 @@ int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w,
   return launch_conv3x3_wino_fwd(a, stream);
 }
 
+size_t rdm_conv3x3_wino_wgrad_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w) {
+  if (channels <= 0 || batch <= 0 || h <= 0 || w <= 0) return 0;
+  return (((wino_wgrad_vy_floats(batch, h, w) * sizeof(float)) + 255) & ~(size_t)255) + (((wino_wgrad_part_floats(batch, h, w, channels) * sizeof(float)) + 255) & ~(size_t)255);
+}
+
+int rdm_conv3x3_wino_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
+                           void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(dy && x && dw && workspace, "conv3x3_wino_wgrad: NULL operand");
+  RDM_CHECK_ARG(d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1, "conv3x3_wino_wgrad: 3x3 / stride 1 / pad 1 only");
+  RDM_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "conv3x3_wino_wgrad: bn_scale and bn_shift go together");
+  RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "conv3x3_wino_wgrad: workspace must be 256-byte aligned");
+  if (workspace_bytes < rdm_conv3x3_wino_wgrad_workspace_bytes(d->in_c, d->batch, d->in_h, d->in_w)) {
+    set_error("conv3x3_wino_wgrad: workspace too small: %zu < %zu", workspace_bytes, rdm_conv3x3_wino_wgrad_workspace_bytes(d->in_c, d->batch, d->in_h, d->in_w));
+    return RDM_ERR_WORKSPACE_TOO_SMALL;
+  }
+  WinoWgrad a{};
+  a.G = dy; a.ldg = d->out_ld; a.N = d->out_c; a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift;
+  a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.vy_floats = wino_wgrad_vy_floats(d->batch, d->in_h, d->in_w);
+  a.Vy = static_cast<float*>(workspace);
+  a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + (((a.vy_floats * sizeof(float)) + 255) & ~(size_t)255));
+  a.part_floats = wino_wgrad_part_floats(d->batch, d->in_h, d->in_w, d->in_c);
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w;
+  return launch_conv3x3_wino_wgrad(a, stream);
+}
+
 int rdm_pack_conv_weight(const float* w, float* wp, int32_t out_c, int32_t in_c, int32_t kh, int32_t kw, int32_t out_c_padded, rdm_stream_t stream) {
   RDM_CHECK_ARG(w && wp && out_c > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c_padded >= out_c, "pack_conv_weight: bad argument");
   return launch_pack_w(w, wp, out_c, in_c, kh * kw, out_c_padded, stream);

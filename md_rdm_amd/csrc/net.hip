@@ -177,6 +177,7 @@ struct NetImpl {
   bool wino_fwd[4] = {false, false, false, false};
   int wino_split[4] = {1, 1, 1, 1};
   size_t winoPartial = 0, winoPartialFloats = 0;
+  size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
@@ -288,6 +289,13 @@ struct NetImpl {
       for (auto& o : winoU[b]) o = a.take<float>((size_t)16 * 48 * bg[b].cb);
     }
     winoPartial = a.take<float>(winoPartialFloats);
+    for (int b = 0; b < 4; ++b)
+      if (wino_fwd[b]) {
+        winoVyFloats = std::max(winoVyFloats, wino_wgrad_vy_floats(B, bg[b].H, bg[b].W));
+        winoQFloats = std::max(winoQFloats, wino_wgrad_part_floats(B, bg[b].H, bg[b].W, bg[b].cb));
+      }
+    winoVy = a.take<float>(winoVyFloats);
+    winoQ = a.take<float>(winoQFloats);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
     for (int b = 0; b < 4; ++b) {
@@ -505,13 +513,23 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const*
       // packed gradients go straight to the caller's tensor; otherwise into a scratch that is unpacked to OIHW afterwards
       float* dW3 = n.opt_packed3x3 ? F(Gr, L.conv2) : at<float>(ws, W.dw3);
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_go, 0));
-      if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
-      WgradArgs w{};
-      w.g = geom3x3(n.B, g.H, g.W, 1);
-      w.G = go; w.ldg = g.ctot; w.N = GROWTH;
-      w.Xs = Y; w.ldx = cb; w.C = cb; w.x_scale = bn2; w.x_shift = bn2 + cb;
-      w.dW = dW3; w.wtap = (long)GROWTH * cb; w.ldw = cb;
-      if ((rc = launch_conv_wgrad(w, side))) return rc;
+      if (n.wino_fwd[b] && !n.opt_no_wino) {
+        // Winograd F(3x3, 2x2): writes the gradient (ordered split reduction, no atomics, no zero fill)
+        WinoWgrad wv{};
+        wv.G = go; wv.ldg = g.ctot; wv.N = GROWTH; wv.A = Y; wv.lda = cb; wv.C = cb; wv.a_scale = bn2; wv.a_shift = bn2 + cb;
+        wv.dW = dW3; wv.wtap = (long)GROWTH * cb; wv.ldw = cb;
+        wv.Vy = at<float>(ws, n.winoVy); wv.vy_floats = n.winoVyFloats; wv.part = at<float>(ws, n.winoQ); wv.part_floats = n.winoQFloats;
+        wv.B = n.B; wv.H = g.H; wv.W = g.W;
+        if ((rc = launch_conv3x3_wino_wgrad(wv, side))) return rc;
+      } else {
+        if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
+        WgradArgs w{};
+        w.g = geom3x3(n.B, g.H, g.W, 1);
+        w.G = go; w.ldg = g.ctot; w.N = GROWTH;
+        w.Xs = Y; w.ldx = cb; w.C = cb; w.x_scale = bn2; w.x_shift = bn2 + cb;
+        w.dW = dW3; w.wtap = (long)GROWTH * cb; w.ldw = cb;
+        if ((rc = launch_conv_wgrad(w, side))) return rc;
+      }
       if (!n.opt_packed3x3 && (rc = launch_unpack_w(dW3, F(Gr, L.conv2), GROWTH, cb, 9, GROWTH, side))) return rc;
     }
     // ---- main: conv2 dgrad -> dZ[par], gated by relu2, with the norm2 backward reductions ----

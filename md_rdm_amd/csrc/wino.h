@@ -13,6 +13,18 @@ struct WinoConv {
   float* partial; size_t partial_floats;          // scratch for the per-split partial outputs, split * B*H*W * 48 floats
   double* stat0; double* stat1;                   // optional: += sum / sum of squares of the output per channel
 };
+struct WinoWgrad {                                // dW[tap][n][c] = sum_m G[m][n] * f(A[pix(m, tap)][c]), written (not accumulated)
+  const float* G; int ldg; int N;                 // output gradient, N <= 48 channels
+  const float* A; int lda; int C;                 // forward input (pre BatchNorm), Cb channels
+  const float* a_scale; const float* a_shift;
+  float* dW; long wtap; int ldw;                  // packed gradient [tap][n][c]
+  float* Vy; size_t vy_floats;                    // scratch: transformed gradient (wino_wgrad_vy_floats)
+  float* part; size_t part_floats;                // scratch: per-split partial sums (wino_wgrad_part_floats)
+  int B, H, W;
+};
+size_t wino_wgrad_vy_floats(int B, int H, int W);
+size_t wino_wgrad_part_floats(int B, int H, int W, int C);
+int launch_conv3x3_wino_wgrad(const WinoWgrad& a, hipStream_t s);
 size_t wino_fwd_workspace_bytes(int C, long M, int split);
 int wino_pick_split(int tiles, int nslab);
 int launch_wino_weight(const float* w_packed, long wtap, int ldw, int N, int C, float* U, hipStream_t s);

@@ -348,6 +348,273 @@ __global__ __launch_bounds__(256) void k_wino_reduce(const float* __restrict__ p
 }
 
 
+
+// =============================================================================================
+// wgrad:  dW[r*3+q][n][c] = sum_m dOut[m][n] * f(Y[m + (r-1) W + (q-1)][c])     (K = all pixels, 48 x Cb outputs per tap)
+// Winograd F(3x3, 2x2): per 2x2 output tile the 3x3 filter gradient is  A3^T [ (G2 dy G2^T) (.) (B^T d B) ] A3  (16 multiplies instead
+// of 36), and the sum over tiles commutes with the output transform:  Q[pos][n][c] = sum_tiles Vy[pos][tile][n] * Vd[pos][tile][c]  are 16
+// GEMMs whose contraction runs over the TILES; dW = A3^T Q A3 is applied once, to the reduced Q.  Vd = B^T d B is the forward kernel's
+// transformed activation (same BatchNorm + ReLU prologue, same padding rule); Vy comes from a pre-pass in A-fragment order.
+//   B^T as above,  G2 = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]],  A3^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
+// Workgroup = 16 positions x 48 n x 64 c (4 consumer waves x 192 accumulators) over a range of tile slabs (16 tiles per slab); the
+// producers gather the 4x4 patches of the slab's 16 tiles for the workgroup's 64 channels, and the LDS image is [pos][tile][64 c] with the
+// 16-float chunks XOR-swizzled by (tile & 3): 16-byte stores and 4-byte fragment reads are both conflict-free.  Partial Q per K split
+// goes to scratch with plain stores; k_wino_wgrad_reduce sums the splits in a fixed order and applies A3^T . A3: no atomics anywhere,
+// the weight gradient is bit-reproducible (the direct row kernel adds 15 split partials with f32 atomics: 68 MB of fabric writes for a
+// 4.7 MB result).
+// =============================================================================================
+// pre-pass: Vy = G2 dy G2^T, A-fragment order [slab][pos][nt][lane = g*16 + l16][e]: n = nt*16 + l16, tile = slab*16 + 4*e + g.
+// One 192-thread workgroup per slab: the slab's 16 tiles x 2x2 pixels x 48 channels go through LDS (coalesced 16-byte loads), thread
+// (nt, lane) then owns channel n of the tiles g, 4+g, 8+g, 12+g and writes its float4 of every position: 1-KiB coalesced stores.
+__global__ __launch_bounds__(192) void k_wino_gradout_transform(const float* __restrict__ G, int ldg, int N, unsigned g_bytes, int B, int H, int W, int TH, int TW,
+                                                                int T, int nslab, float* __restrict__ Vy) {
+  __shared__ float gs[16][4][48 + 1];
+  const int slab = blockIdx.x, tid = threadIdx.x;
+  const int tpi = TH * TW;
+  const __amdgpu_buffer_rsrc_t srd = wsrd(G, g_bytes);
+  for (int i = tid; i < 16 * 4 * 12; i += 192) {                   // (tile, pixel, channel quad): 12 lanes cover a pixel's 48 channels
+    const int quad = i % 12, px = (i / 12) & 3, tl = i / 48;
+    const long t = (long)slab * 16 + tl;
+    const int b = (int)(t / tpi), rem = (int)(t - (long)b * tpi);
+    const int ty = rem / TW, tx = rem - ty * TW;
+    const int y = 2 * ty + (px >> 1), x = 2 * tx + (px & 1);
+    const bool ok = t < T && y < H && x < W && quad * 4 < N;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, ok ? (int)((unsigned)((b * H + y) * W + x) * (unsigned)(ldg * 4) + (unsigned)(quad * 16)) : (int)WOOB, 0, 0);
+    gs[tl][px][quad * 4 + 0] = __uint_as_float(v.x); gs[tl][px][quad * 4 + 1] = __uint_as_float(v.y);
+    gs[tl][px][quad * 4 + 2] = __uint_as_float(v.z); gs[tl][px][quad * 4 + 3] = __uint_as_float(v.w);
+  }
+  __syncthreads();
+  const int nt = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4, n = nt * 16 + l16;
+  f32x4 out[16];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int tl = 4 * e + g;
+    const float y00 = gs[tl][0][n], y01 = gs[tl][1][n], y10 = gs[tl][2][n], y11 = gs[tl][3][n];
+    float t2[4][2];                                               // G2 dy: rows
+    t2[0][0] = y00; t2[1][0] = 0.5f * (y00 + y10); t2[2][0] = 0.5f * (y00 - y10); t2[3][0] = y10;
+    t2[0][1] = y01; t2[1][1] = 0.5f * (y01 + y11); t2[2][1] = 0.5f * (y01 - y11); t2[3][1] = y11;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out[i * 4 + 0][e] = t2[i][0]; out[i * 4 + 1][e] = 0.5f * (t2[i][0] + t2[i][1]);
+      out[i * 4 + 2][e] = 0.5f * (t2[i][0] - t2[i][1]); out[i * 4 + 3][e] = t2[i][1];
+    }
+  }
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x4*>(Vy + ((((long)slab * 16 + pos) * 3 + nt) * 64 + lane) * 4) = out[pos];
+}
+
+struct WinoWgradArgs {
+  const float* A; int lda; int C;                 // forward input Y (pre BatchNorm), Cb channels
+  const float* a_scale; const float* a_shift;
+  const float* Vy;                                // transformed output gradient, fragment order
+  float* part;                                    // [split][16 pos][48 n][Cpad]   (Cpad = 64 * column blocks)
+  int B, H, W, TH, TW, T, nslab, split, Cpad;
+  unsigned a_bytes;
+};
+
+template <bool BNRELU>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_wgrad_kernel(WinoWgradArgs p) {
+  __shared__ __attribute__((aligned(1024))) float smem[2 * 16 * 16 * 64];        // Vd double buffer [pos][tile][64 c]: 2 x 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int per = (p.nslab + p.split - 1) / p.split;
+  const int s_begin = blockIdx.y * per, s_end = min(p.nslab, s_begin + per);
+  const int c0 = blockIdx.x * 64;
+  const bool producer = wave >= 4;
+  const int pos0 = (wave & 3) * 4;
+  f32x4 acc[4][3][4];                               // [position][n-tile][c-tile]
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[pp][nt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    if (producer) {
+      // ---- producer: thread -> channel quad cq (of the workgroup's 64 channels) of tile tl of the slab; 16 lanes cover a pixel's 256 bytes ----
+      const int ptid = tid - 256, tl = ptid >> 4, cq = ptid & 15;
+      const bool cok = c0 + cq * 4 < p.C;
+      const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (BNRELU && cok) { sc = *reinterpret_cast<const f32x4*>(p.a_scale + c0 + cq * 4); sh = *reinterpret_cast<const f32x4*>(p.a_shift + c0 + cq * 4); }
+      const unsigned coff = (unsigned)((c0 + cq * 4) * 4);
+      // tile cursor (b, ty, tx) of this thread's tile of the current slab; one slab = 16 tiles further
+      int tb, tty, ttx;
+      {
+        const int t = s_begin * 16 + tl, tpi = p.TH * p.TW;
+        tb = t / tpi;
+        const int rem = t - tb * tpi;
+        tty = rem / p.TW; ttx = rem - tty * p.TW;
+      }
+      unsigned voff[16];
+      float hi[16];
+      auto place = [&]() {                           // offsets / padding bounds of the cursor's patch, then advance the cursor by one slab
+        const bool tok = tb < p.B && cok;
+        const unsigned base = (unsigned)((tb * p.H + 2 * tty - 1) * p.W + 2 * ttx - 1) * (unsigned)(p.lda * 4) + coff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = tok && (unsigned)(2 * tty - 1 + i) < (unsigned)p.H && (unsigned)(2 * ttx - 1 + j) < (unsigned)p.W;
+            voff[i * 4 + j] = ok ? base + (unsigned)((i * p.W + j) * p.lda * 4) : WOOB;
+            hi[i * 4 + j] = ok ? __builtin_inff() : 0.f;
+          }
+        ttx += 16;
+        while (ttx >= p.TW) { ttx -= p.TW; ++tty; }
+        while (tty >= p.TH) { tty -= p.TH; ++tb; }
+      };
+      float rv[4][16];
+      auto load_raw = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srdA, (int)voff[q], 0, 0);
+          rv[0][q] = __uint_as_float(v.x); rv[1][q] = __uint_as_float(v.y); rv[2][q] = __uint_as_float(v.z); rv[3][q] = __uint_as_float(v.w);
+        }
+      };
+      float hic[16];                                 // padding bounds of the patch that is in flight (place() already describes the next one)
+      auto transform_store = [&](float* Vb) {
+        if (BNRELU) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rv[c][q] = __builtin_amdgcn_fmed3f(fmaf(rv[c][q], sc[c], sh[c]), 0.f, hic[q]);
+        }
+#define RDM_WINO_1D(v, i0, i1, i2, i3)                                                        \
+        { const float d0 = v[i0], d1 = v[i1], d2 = v[i2], d3 = v[i3];                         \
+          v[i0] = d0 - d2; v[i1] = d1 + d2; v[i2] = d2 - d1; v[i3] = d1 - d3; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) RDM_WINO_1D(rv[c], j, 4 + j, 8 + j, 12 + j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) RDM_WINO_1D(rv[c], 4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3)
+        }
+#undef RDM_WINO_1D
+        const int chunk = (cq >> 2) ^ (tl & 3);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+          *reinterpret_cast<f32x4*>(Vb + ((pos * 16 + tl) * 64 + chunk * 16 + (cq & 3) * 4)) = f32x4{rv[0][pos], rv[1][pos], rv[2][pos], rv[3][pos]};
+      };
+      place();
+      load_raw();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hic[q] = hi[q];
+      transform_store(smem);
+      place();                                         // slab s_begin + 1 (past the end: harmless loads of real tiles or of nothing)
+      load_raw();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hic[q] = hi[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) {
+          transform_store(smem + (buf ^ 1) * (16 * 16 * 64));
+          place();
+          load_raw();
+#pragma unroll
+          for (int q = 0; q < 16; ++q) hic[q] = hi[q];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // ---- consumer: positions pos0 .. pos0 + 3; A = Vy fragments (global, 1 KiB each), B = Vd fragments (LDS, one float per k-step) ----
+      const __amdgpu_buffer_rsrc_t srdY = wsrd(p.Vy, (unsigned)((size_t)p.nslab * 16 * 3 * 1024));
+      const int lane16 = lane * 16;
+      auto load_a = [&](int s, int pos, f32x4 (&a)[3]) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srdY, lane16, ((s * 16 + pos) * 3 + nt) * 1024, 0);
+          a[nt] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+      };
+      // B fragment of c-tile ct, k-step e: tile 4e + g, channel ct*16 + l16 -> chunk ct ^ (tile & 3) = ct ^ g
+      auto load_b = [&](const float* Vb, int pos, int ct) {
+        f32x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = Vb[(pos * 16 + 4 * e + g) * 64 + ((ct ^ g) * 16) + l16];
+        return b;
+      };
+      f32x4 aq[2][3], bq[2];
+      load_a(s_begin, pos0, aq[0]);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int s = s_begin; s < s_end; ++s) {
+        const float* Vb = smem + ((s - s_begin) & 1) * (16 * 16 * 64);
+        bq[0] = load_b(Vb, pos0, 0);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp < 3) load_a(s, pos0 + pp + 1, aq[(pp + 1) & 1]);
+          else load_a(min(s + 1, s_end - 1), pos0, aq[0]);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const int cur = (pp * 4 + ct) & 1;
+            if (ct < 3) bq[cur ^ 1] = load_b(Vb, pos0 + pp, ct + 1);
+            else if (pp < 3) bq[cur ^ 1] = load_b(Vb, pos0 + pp + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int nt = 0; nt < 3; ++nt)
+                acc[pp][nt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[pp & 1][nt][e], bq[cur][e], acc[pp][nt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+  // ---- partial Q of this K split: plain stores, [split][pos][n][Cpad] (D layout: row n = nt*16 + 4g + r, column c = ct*16 + l16) ----
+  if (!producer) {
+    float* dst = p.part + (((long)blockIdx.y * 16 + pos0) * 48) * p.Cpad + c0;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) dst[((long)pp * 48 + nt * 16 + 4 * g + r) * p.Cpad + ct * 16 + l16] = acc[pp][nt][ct][r];
+  }
+}
+
+// Q = sum of the split partials (fixed order), dW = A3^T Q A3 -> packed gradient [tap][n][c]; a thread owns 4 consecutive channels
+__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ part, int split, int Cpad, int N, int C, float* __restrict__ dW, long wtap, int ldw) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = Cpad / 4;
+  const int c = (int)(idx % c4) * 4, n = (int)(idx / c4);
+  if (n >= N || c >= C) return;
+  f32x4 q[16];
+  const long stride = (long)16 * 48 * Cpad;
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos) {
+    const float* src = part + ((long)pos * 48 + n) * Cpad + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    int s = 1;
+    for (; s + 3 < split; s += 4) {                                // four loads in flight, added in split order
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + s * stride), a1 = *reinterpret_cast<const f32x4*>(src + (s + 1) * stride);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (s + 2) * stride), a3 = *reinterpret_cast<const f32x4*>(src + (s + 3) * stride);
+      v += a0; v += a1; v += a2; v += a3;
+    }
+    for (; s < split; ++s) v += *reinterpret_cast<const f32x4*>(src + s * stride);
+    q[pos] = v;
+  }
+  f32x4 t[3][4];                                                  // A3^T Q: rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { t[0][j] = q[j] + q[4 + j] + q[8 + j]; t[1][j] = q[4 + j] - q[8 + j]; t[2][j] = q[4 + j] + q[8 + j] - q[12 + j]; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const f32x4 w3[3] = {t[r][0] + t[r][1] + t[r][2], t[r][1] - t[r][2], t[r][1] + t[r][2] - t[r][3]};
+#pragma unroll
+    for (int qq = 0; qq < 3; ++qq)
+      *reinterpret_cast<f32x4*>(dW + (long)(r * 3 + qq) * wtap + (long)n * ldw + c) = w3[qq];      // C is a multiple of 4: a quad is inside or outside
+  }
+}
+
 }  // namespace
 
 size_t wino_fwd_workspace_bytes(int C, long M, int split) {
@@ -417,6 +684,55 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
       RDM_LAUNCH_OK();
     } else if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
   }
+  return 0;
+}
+
+int wino_wgrad_split(int nslab, int cblocks) {
+  // one workgroup per CU: (column blocks x splits) should fill the 256 CUs in whole rounds; every split keeps >= 16 slabs
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 64 && sp * 16 <= std::max(nslab, 16); ++sp) {
+    const long rounds = ((long)cblocks * sp + 255) / 256;
+    const double cost = rounds * ((nslab + sp - 1) / sp + 2.0) + 0.8 * sp;       // + the split's partial Q through HBM (~0.8 slab-times)
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+size_t wino_wgrad_vy_floats(int B, int H, int W) {
+  const long T = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return (size_t)((T + 15) / 16) * 16 * 3 * 64 * 4;
+}
+size_t wino_wgrad_part_floats(int B, int H, int W, int C) {
+  const long T = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const int cblocks = (C + 63) / 64;
+  return (size_t)wino_wgrad_split((int)((T + 15) / 16), cblocks) * 16 * 48 * cblocks * 64;
+}
+
+int launch_conv3x3_wino_wgrad(const WinoWgrad& a, hipStream_t s) {
+  RDM_CHECK_ARG(a.N >= 1 && a.N <= 48 && a.N % 4 == 0 && a.C >= 4 && a.C % 4 == 0, "winograd 3x3 wgrad: N (%d) <= 48, N and C (%d) multiples of 4", a.N, a.C);
+  RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldg % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.G & 15) == 0, "winograd 3x3 wgrad: strides multiples of 4 floats, tensors 16-byte aligned");
+  const long M = (long)a.B * a.H * a.W;
+  const long ab = ((M - 1) * a.lda + a.C) * 4, gb = ((M - 1) * a.ldg + a.N) * 4;
+  if (ab >= 0xFFFFFFFFL || gb >= 0xFFFFFFFFL) { set_error("winograd 3x3 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  const int TH = (a.H + 1) / 2, TW = (a.W + 1) / 2;
+  const int T = a.B * TH * TW, nslab = cdiv(T, 16), cblocks = cdiv(a.C, 64);
+  const int split = wino_wgrad_split(nslab, cblocks);
+  RDM_CHECK_ARG(a.vy_floats >= (size_t)nslab * 16 * 3 * 256 && a.part_floats >= (size_t)split * 16 * 48 * cblocks * 64, "winograd 3x3 wgrad: scratch too small");
+  hipLaunchKernelGGL(k_wino_gradout_transform, dim3((unsigned)nslab), dim3(192), 0, s, a.G, a.ldg, a.N, (unsigned)gb, a.B, a.H, a.W, TH, TW, T, nslab, a.Vy);
+  RDM_LAUNCH_OK();
+  WinoWgradArgs k{};
+  k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.Vy = a.Vy; k.part = a.part;
+  k.B = a.B; k.H = a.H; k.W = a.W; k.TH = TH; k.TW = TW; k.T = T; k.nslab = nslab; k.split = split; k.Cpad = cblocks * 64; k.a_bytes = (unsigned)ab;
+  void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 10);
+  RDM_CENSUS("conv3x3_wino_wgrad_kernel/%s", a.a_scale ? "bn1" : "bn0");
+  dim3 grid((unsigned)cblocks, (unsigned)split);
+  if (a.a_scale) hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel<true>, grid, dim3(512), 0, s, k);
+  else hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel<false>, grid, dim3(512), 0, s, k);
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  RDM_CHECK_ARG(a.ldw % 4 == 0 && a.wtap % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "winograd 3x3 wgrad: the packed gradient must be 16-byte aligned with strides that are multiples of 4");
+  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)cdiv((long)48 * cblocks * 16, 256)), dim3(256), 0, s, a.part, split, cblocks * 64, a.N, a.C, a.dW, a.wtap, a.ldw);
+  RDM_LAUNCH_OK();
   return 0;
 }
 

@@ -84,3 +84,56 @@ def test_wino_forward_vs_float64(case):
     assert torch.equal(out.cpu()[:, :N], outs[2][1])
     _RAN.add(case)
 
+
+
+def ref3x3_wgrad(gy, a):
+    B, H, W, N = gy.shape
+    Cc = a.shape[3]
+    ap = F.pad(a, (0, 0, 1, 1, 1, 1))
+    g2 = gy.reshape(-1, N).t().contiguous()
+    return torch.stack([g2 @ ap[:, r:r + H, q:q + W, :].reshape(-1, Cc) for r in range(3) for q in range(3)])
+
+
+WGRAD_CASES = [
+    # B, H, W, Cb, ld, N, ldg, bn
+    (4, 57, 76, 2736, 2736, 48, 384, True),      # dense_e2's conv2 (RDM_Net.py:526), gradient = a 48-channel slice of the 384-wide block gradient
+    (16, 29, 38, 1392, 1392, 48, 768, True),     # dense_e3's conv2 at the bench batch (RDM_Net.py:528)
+    (3, 8, 10, 384, 400, 48, 48, True),          # decoder-sized map, NaN behind the contracted prefix
+    (1, 7, 5, 100, 100, 40, 40, False),          # odd sizes, ragged last 64-channel block, N < 48, no prologue
+    (2, 9, 9, 64, 64, 48, 48, True),             # tile rows shorter than a 16-tile slab (several cursor wraps per slab)
+    (1, 1, 1, 16, 16, 16, 16, True),             # single pixel
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[f"g{i}" for i in range(len(WGRAD_CASES))])
+def test_wino_wgrad_vs_float64(case):
+    """conv3x3_wino_wgrad_kernel (Winograd F(3x3, 2x2), the contraction runs over the tiles) vs a float64 evaluation; written, not
+    accumulated; bit-reproducible."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cb, ld, N, ldg, bn = case
+    g = torch.Generator().manual_seed(6000 + Cb + W)
+    x = torch.randn(B, H, W, ld, generator=g)
+    if ld > Cb:
+        x[..., Cb:] = float("nan")
+    go = torch.randn(B, H, W, ldg, generator=g)
+    if ldg > N:
+        go[..., N:] = float("nan")
+    sc = torch.rand(Cb, generator=g) + 0.5
+    sh = torch.randn(Cb, generator=g) * 0.3
+    a = (torch.relu(x[..., :Cb] * sc + sh) if bn else x[..., :Cb]).double()
+    want = ref3x3_wgrad(go[..., :N].double(), a)
+    d = ConvDesc(B, H, W, Cb, ld, N, ldg, 3, 3, 1, 1, 1, 1)
+    xg, gog, scg, shg = x.to(dev), go.to(dev), sc.to(dev), sh.to(dev)
+    nb = int(L.rdm_conv3x3_wino_wgrad_workspace_bytes(Cb, B, H, W))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((9, N, Cb), float("nan"), device=dev)
+        check(L.rdm_conv3x3_wino_wgrad(C.byref(d), ptr(gog), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), ptr(ws), nb, stream()))
+        outs.append(dw.cpu())
+    assert rel(outs[0].double(), want) < TOL
+    assert torch.equal(outs[0], outs[1])                                   # no atomics: bit-reproducible
+    _RAN.add(("wgrad",) + case)

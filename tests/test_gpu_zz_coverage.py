@@ -5,7 +5,7 @@ import torch
 import conftest
 
 pytestmark = pytest.mark.gpu
-NEED = {"test_gpu_conv": 4 + 4 + 8 + 2, "test_gpu_wino": 6}          # headline-size parity cases each operator-level module must have run
+NEED = {"test_gpu_conv": 4 + 4 + 8 + 2, "test_gpu_wino": 6 + 6}          # headline-size parity cases each operator-level module must have run
 
 
 def test_every_headline_kernel_variant_was_launched_by_a_parity_test():
@@ -37,7 +37,7 @@ def test_every_headline_kernel_variant_was_launched_by_a_parity_test():
         step = _lib.census()
     finally:
         L.rdm_census_enable(0)
-    assert len(step) >= 10 and any(k.startswith("conv_wgrad3_row_kernel") for k in step) and any("px256" in k for k in step) and any(
-        k.startswith("conv1x1_dma256_kernel") for k in step) and any(k.startswith("conv3x3_wino_fwd_kernel") for k in step), sorted(step)
+    assert len(step) >= 10 and any("px256" in k for k in step) and any(
+        k.startswith("conv1x1_dma256_kernel") for k in step) and any(k.startswith("conv3x3_wino_fwd_kernel") for k in step) and any(k.startswith("conv3x3_wino_wgrad_kernel") for k in step), sorted(step)
     missing = sorted(k for k in step if by_tests.get(k, 0) == 0)
     assert not missing, "kernel variants of the headline step that no operator-level parity test launched: %r" % missing

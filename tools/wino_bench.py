@@ -32,3 +32,11 @@ for (B, H, W, Cb) in shapes:
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         t = timeit(lambda: check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(y), ptr(w), ptr(sc), ptr(sh), ptr(out), None, None, ptr(ws), nb, sp, stream())))
         print(f"    winograd split {sp}: {t:.3f} ms = {fl / t / 1e9:.1f} TFLOP/s (algorithmic)", flush=True)
+    # weight gradient of the same conv: direct row kernel (rdm_conv2d_wgrad, accumulating with f32 atomics) vs Winograd F(3x3,2x2)
+    go = torch.randn(M, 48, device=dev); dw = torch.zeros(9, 48, Cb, device=dev)
+    t = timeit(lambda: check(L.rdm_conv2d_wgrad(C.byref(d), ptr(go), ptr(y), ptr(sc), ptr(sh), ptr(dw), stream())))
+    print(f"    wgrad direct {t:.3f} ms = {fl / t / 1e9:.1f} TFLOP/s", flush=True)
+    nb = int(L.rdm_conv3x3_wino_wgrad_workspace_bytes(Cb, B, H, W))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    t = timeit(lambda: check(L.rdm_conv3x3_wino_wgrad(C.byref(d), ptr(go), ptr(y), ptr(sc), ptr(sh), ptr(dw), ptr(ws), nb, stream())))
+    print(f"    wgrad winograd {t:.3f} ms = {fl / t / 1e9:.1f} TFLOP/s (algorithmic)", flush=True)
