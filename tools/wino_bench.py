@@ -2,7 +2,10 @@
 shapes at the bench batch, BN-ReLU prologue on.  Prints ms and algorithmic TFLOP/s (2*M*48*9*C / time)."""
 import ctypes as C, sys, torch
 sys.path.insert(0, ".")
+import os
 from md_rdm_amd import _lib
+if os.environ.get("RDM_LIB"):                        # A/B of differently built libraries (development only)
+    _lib.LIB_PATH = os.environ["RDM_LIB"]
 from md_rdm_amd._lib import ConvDesc, check, ptr, stream
 L = _lib.lib()
 dev = torch.device("cuda:0")
