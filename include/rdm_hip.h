@@ -247,8 +247,12 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                of a flat gradient buffer instead of ~160 per-tensor fills inside the plan).
  *   RDM_NET_OPT_DIRECT_3X3       every 3x3 convolution on the direct implicit-GEMM kernels (default 0: the blocks with >= 16 384 pixels -
  *                                dense_e2 / dense_e3 at the headline geometry - run Winograd F(2x2, 3x3), csrc/wino.hip; same result to
- *                                float32 rounding, tests/test_gpu_wino.py). */
-typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3 } rdm_net_option;
+ *                                float32 rounding, tests/test_gpu_wino.py).
+ *   RDM_NET_OPT_DETERMINISTIC    ordered reductions everywhere (for tests): no K split (so no f32 atomics with more than one contributor),
+ *                                channel statistics and the dgrad gate / BatchNorm-backward sums as separate passes with a fixed summation
+ *                                order, no layer pipelining.  Two runs on the same inputs then give bit-identical gradients; several
+ *                                times slower than the default. */
+typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -22,6 +22,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+thread_local bool t_deterministic = false;
 bool g_census_on = false;
 namespace {
 std::mutex g_census_mu;

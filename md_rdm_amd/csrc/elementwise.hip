@@ -66,6 +66,7 @@ static int rows_per_block(long M, int C) {
   // contention per address: aim for ~48 chunks (measured: 143 chunks made a 13 MB reduction take
   // 28 us, atomics-bound), but never fewer than 16 or more than 512 rows per workgroup
   (void)C;
+  if (t_deterministic) return (int)std::min<long>(M, 0x7FFFFFF0L);      // one row chunk per column group: fixed order, one add onto the zeroed slot
   long rpb = (M + 47) / 48;
   rpb = (rpb + 15) / 16 * 16;
   if (rpb < 16) rpb = 16;

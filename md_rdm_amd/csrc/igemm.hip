@@ -1093,7 +1093,23 @@ static void launch_fwd_epi(const FwdArgs& a, int cfg, int split, hipStream_t s) 
   else launch_fwd_cfg<2, 3, 4, 1, TAPS, BK_, EPI>(a, split, s);                 // 128 x 48
 }
 
+static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s);
+
 int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s) {
+  if (!t_deterministic) return launch_conv_fwd_impl(a_in, b_kstrided, epi, s);
+  // deterministic mode: no K split, statistics / gate as separate ordered passes over the stored result
+  FwdArgs a = a_in;
+  RDM_CHECK_ARG(!a.accumulate && !a.add_out, "deterministic mode: accumulate / add_out launches are not available (the plan disables layer pipelining)");
+  a.split_k = 1;
+  const Epilogue e2 = (epi == EPI_STORE_STATS || epi == EPI_MASK_STATS) ? EPI_STORE : epi;
+  const int rc = launch_conv_fwd_impl(a, b_kstrided, e2, s);
+  if (rc < 0) return rc;
+  if (epi == EPI_STORE_STATS) return launch_colstats(a.out, a.ldc, a.M, a.N, a.stat0, a.stat1, s);
+  if (epi == EPI_MASK_STATS) return launch_mask_stats(a.out, a.ldc, a.X, a.ldx, a.x_scale, a.x_shift, a.M, a.N, a.stat0, a.stat1, s);
+  return rc;
+}
+
+static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s) {
   FwdArgs a = a_in;
   RDM_CHECK_ARG(a.C % 16 == 0 && a.C > 0, "conv: contracted channels (%d) must be a positive multiple of 16", a.C);
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldw % 4 == 0 && a.wtap % 4 == 0, "conv: strides must be multiples of 4 floats");
@@ -1247,6 +1263,7 @@ static int pick_split_row3(long tiles0, long kslabs) {
 
 int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   WgradArgs a = a_in;
+  if (t_deterministic) a.split_k = 1;                     // one workgroup per output element: its atomic add onto the zeroed gradient is exact
   RDM_CHECK_ARG(a.N % 4 == 0 && a.C % 4 == 0, "wgrad: N (%d) and C (%d) must be multiples of 4", a.N, a.C);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0, "wgrad: strides must be multiples of 4 floats");
   RDM_CHECK_ARG(((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "wgrad: operands must be 16-byte aligned");

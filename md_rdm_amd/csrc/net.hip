@@ -181,6 +181,7 @@ struct NetImpl {
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
+  int opt_det = 0;             // RDM_NET_OPT_DETERMINISTIC: ordered reductions everywhere (tests), see DetScope
   int opt_no_wino = 0;         // RDM_NET_OPT_DIRECT_3X3: keep the direct implicit-GEMM kernels everywhere (A/B and tests)
   int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
   int opt_prezeroed = 0;       // RDM_NET_OPT_GRADS_PREZEROED: every gradient tensor is zero when backward stage 0 starts
@@ -387,7 +388,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
   // everything except the newest 48 is already final while layer i is still running - so that bulk
   // ("part A") runs one layer ahead on the side stream, and only the 48-channel remainder ("part B",
   // 3 K-slabs) stays on the critical path.  Both parts add atomically into a zeroed Y.
-  const bool pipelined = !fuse_stats(g.M, g.cb) && layers > 1 && g_variant != 8;
+  const bool pipelined = !fuse_stats(g.M, g.cb) && layers > 1 && g_variant != 8 && !n.opt_det;   // part A / part B add atomically: not in deterministic mode
   hipStream_t side = n.side;
   int rc;
   if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[1], s));        // statistics of the block's input channels are final ("layer -1")
@@ -661,6 +662,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   if (option == RDM_NET_OPT_PACKED_3X3) n->opt_packed3x3 = value != 0;
   else if (option == RDM_NET_OPT_GRADS_PREZEROED) n->opt_prezeroed = value != 0;
   else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
+  else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }
@@ -731,6 +733,7 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
     RDM_CHECK_ARG(T[i] != nullptr || reg().t[i].numel == 0, "tensor %d (%s) is NULL", i, reg().t[i].name.c_str());
   hipStream_t s = stream;
   n.training_saved = training;
+  DetScope det(n.opt_det != 0);
   int rc;
   if (training) RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.stats_begin), 0, n.stats_end - n.stats_begin, s));
   // the 78 3x3 weights are re-packed to [tap][out][in] once per forward, off the critical path: on the
@@ -978,6 +981,7 @@ int rdm_net_backward_stage(rdm_net* net, const float* dlogits, void* const* T, v
   RDM_CHECK_ARG(stage != 0 || dlogits != nullptr, "dlogits is NULL");
   NetImpl& n = *reinterpret_cast<NetImpl*>(net);
   if (ws_bytes < n.total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  DetScope det(n.opt_det != 0);
   return backward_stage(n, stage, dlogits, ws, T, Gr, stream);
 }
 
@@ -988,6 +992,7 @@ int rdm_net_backward(rdm_net* net, const float* dlogits, void* const* T, void* c
   RDM_CHECK_ARG(first_seg != 0 || dlogits != nullptr, "dlogits is NULL");
   NetImpl& n = *reinterpret_cast<NetImpl*>(net);
   if (ws_bytes < n.total) { set_error("workspace too small: %zu < %zu", ws_bytes, n.total); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  DetScope det(n.opt_det != 0);
   for (int st = 0; st < (int)reg().stages.size(); ++st) {
     const int seg = reg().stages[st].seg;
     if (seg < first_seg || seg > last_seg) continue;

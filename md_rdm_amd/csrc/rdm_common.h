@@ -51,6 +51,17 @@ constexpr int g_variant = 0;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Deterministic reduction mode (rdm_net_set_option RDM_NET_OPT_DETERMINISTIC; tests): while a plan call that asked for it is running on
+// this thread, the launchers never split K (one workgroup owns every output element), take channel statistics with ONE row chunk per
+// column group (a fixed summation order instead of f64 atomics from many workgroups) and gate / reduce the dgrad results in a separate
+// ordered pass.  Slower, bit-reproducible.  Thread-local and scoped (DetScope): no process-wide mutable state.
+extern thread_local bool t_deterministic;
+struct DetScope {
+  bool prev;
+  explicit DetScope(bool on) : prev(t_deterministic) { t_deterministic = on; }
+  ~DetScope() { t_deterministic = prev; }
+};
+
 // Launch census (rdm_census_*): while enabled, every MFMA launcher records WHICH kernel variant it picked (tile size, halo length,
 // epilogue, split) under a readable name, so the parity tests can assert that the variants the headline geometry selects were the
 // ones they compared with the oracle.  Off by default: one predictable branch per launch.

@@ -676,13 +676,17 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   if (split > 1 || a.stat0) {
-    // split > 1: ordered sum of the partials into the output slice (+ statistics); split == 1 with statistics: one pass over the slice
-    const float* src = split > 1 ? a.partial : nullptr;
+    // split > 1: ordered sum of the partials into the output slice (+ statistics); split == 1 with statistics: one pass over the slice.
+    // Deterministic mode: the statistics come from the ordered column pass instead of the reduction's per-workgroup f64 atomics.
+    const bool stats_apart = a.stat0 && (split == 1 || t_deterministic);
     if (split > 1) {
       const int rpb = 84;                                     // 21 row lanes x 4 rows
-      hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, s, src, split, M, a.N, a.out, a.ldc, a.stat0, a.stat1, rpb);
+      hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, s, a.partial, split, M, a.N, a.out, a.ldc, stats_apart ? nullptr : a.stat0,
+                         stats_apart ? nullptr : a.stat1, rpb);
       RDM_LAUNCH_OK();
-    } else if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
+    }
+    if (stats_apart)
+      if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
   }
   return 0;
 }

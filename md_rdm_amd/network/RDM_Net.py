@@ -322,6 +322,7 @@ class DepthEstimationNet(BaseModel):
         self._names = None
         self.direct_grads = False  # True: backward writes straight into the flat gradient buffer (fast path of our harness)
         self.grad_ready_hook = None  # callable(stage) fired after each backward stage has been enqueued (DP overlap)
+        self.deterministic = False  # True (set before the first forward): RDM_NET_OPT_DETERMINISTIC - ordered reductions, bit-reproducible gradients (tests)
         self.precision = "f32"     # "bf16": eval-mode forward on the bf16 MFMA path (set_precision)
         self._bf16_w = None        # prepared bf16 weights + folded BatchNorm affines (rdm_net_bf16_prepare)
         self._bf16_stale = True
@@ -410,13 +411,15 @@ class DepthEstimationNet(BaseModel):
             self.flatten_parameters()
 
     def _plan(self, B, H, W):
-        key = (B, H, W)
+        key = (B, H, W, bool(self.deterministic))
         if key not in self._plans:
             L = _lib.lib()
             h = C.c_void_p()
             _lib.check(L.rdm_net_create(B, H, W, C.byref(h)))
             _lib.check(L.rdm_net_set_option(h, 1, 1))         # RDM_NET_OPT_PACKED_3X3: flatten_parameters keeps the 3x3 weights packed
             _lib.check(L.rdm_net_set_option(h, 2, 1))         # RDM_NET_OPT_GRADS_PREZEROED: _native_backward fills the flat gradient buffer once
+            if self.deterministic:
+                _lib.check(L.rdm_net_set_option(h, 4, 1))     # RDM_NET_OPT_DETERMINISTIC
             oh, ow = C.c_int32(), C.c_int32()
             _lib.check(L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)))
             self._plans[key] = (h, int(L.rdm_net_workspace_bytes(h)), oh.value, ow.value)

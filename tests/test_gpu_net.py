@@ -33,9 +33,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def make_model(dev, train=True):
+def make_model(dev, train=True, deterministic=False):
     from md_rdm_amd.network.RDM_Net import DepthEstimationNet
     m = DepthEstimationNet()
+    m.deterministic = deterministic                    # RDM_NET_OPT_DETERMINISTIC: ordered reductions (set before the first forward)
     filler.fill_state_dict(m.state_dict())
     m = m.to(dev)
     return m.train() if train else m.eval()
@@ -120,11 +121,17 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
     the handful the float32 oracle happens to evaluate without a flip (d_1 denselayer24: 2e-5), where its own error says nothing
     about the noise level; the floors are 2x the typical L2 level and 4x the p90 norm error.
     (b) cannot be tighter than geometry allows: | ||g'|| - ||g|| | / ||g|| = e cos(theta) + O(e^2) for an error of relative length e at
-    angle theta to the gradient, and an error that is NOT systematically aligned with the gradient has |cos(theta)| ~ 1 / sqrt(numel) -
-    a 288-element BatchNorm bias with e = 1.2 % lands at 2e-3 once in a while (seen: 2.3e-3, a run-to-run effect of the atomics'
-    summation order picking different ReLU flips).  So a tensor may also pass (b) with  e x 4 / sqrt(numel) + e^2  (4 sigma of a random
-    direction): 2.9e-3 for that bias, 5e-5 - i.e. irrelevant next to the floor - for a 1 M-element weight, where only a SYSTEMATIC
-    error (wrong scale, missing term) could move the norm."""
+    angle theta to the gradient, and an error that is NOT systematically aligned with the gradient has |cos(theta)| ~ 1 / sqrt(numel):
+    a tensor may also pass (b) with  e x 4 / sqrt(numel) + e^2  (4 sigma of a random direction) - 6.7e-3 for a 288-element BatchNorm bias
+    at e = 2.6 %, 5e-5 (irrelevant next to the floor) for a 1 M-element weight, where only a SYSTEMATIC error could move the norm.
+    Round 3 built the deterministic reduction mode the round-2 review asked for (RDM_NET_OPT_DETERMINISTIC: no K split, ordered
+    statistics; test_deterministic_mode_is_bit_reproducible... below) and ran this criterion in it: the verdict is then the same on
+    every run, but the floors cannot come down - a fixed, purely sequential float32 summation order has MORE rounding error than the
+    split partial sums (which add pairwise), so it flips more ReLU decisions: seven BatchNorm tensors of 96-720 elements sit at
+    e = 2.2-2.6 % with 1.7e-3 .. 6.2e-3 norm deviation (inside the geometric bound, outside any flat floor that would still mean
+    something for the large tensors), d_1.denselayer24.conv1.weight at e = 1.55 %.  The noise is the discrete flip noise of ANY float32
+    evaluation (the oracle's own float32 run shows it), not an ordering artefact.  This test therefore keeps measuring the SHIPPED mode
+    with the floors of round 2; what the deterministic mode adds is bit-reproducibility, asserted separately."""
     from md_rdm_amd import harness
     K_L2, FLOOR_L2, K_NORM, FLOOR_NORM = 2.0, 1.5e-2, 3.0, 1.5e-3
     B = 2
@@ -158,6 +165,33 @@ def test_gradients_per_tensor_vs_float64_oracle_and_reference_norms(dev, net_gol
     bad = [t for t in report if t[1] > K_L2 * t[2] + FLOOR_L2 or t[3] > max(K_NORM * t[4] + FLOOR_NORM, t[1] * 4.0 / t[5] ** 0.5 + t[1] ** 2)]
     assert not bad, "per-tensor gradient parity failed for %d tensors (name, l2 hip, l2 f32, norm hip, norm f32, numel): %r" % (
         len(bad), sorted(bad, key=lambda t: -t[1])[:5])
+
+
+def test_deterministic_mode_is_bit_reproducible_and_agrees_with_the_default_mode(dev):
+    """RDM_NET_OPT_DETERMINISTIC: two train steps on the same inputs from the same weights - in two separate model instances - give
+    BIT-IDENTICAL logits, gradients (all 485 tensors) and post-AdamW weights; against the default mode (split-K atomics, fused statistics,
+    pipelined small blocks) the forward agrees to float32 rounding and every gradient tensor to the ReLU-flip noise level."""
+    from md_rdm_amd import harness
+    x, y = filler.synthetic_batch(2, 228, 228, seed=9)
+    xa, ya = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    runs = []
+    for det in (True, True, False):
+        m = make_model(dev, deterministic=det)
+        m.flatten_parameters()
+        m.direct_grads = True
+        opt = harness.FusedAdamW(m, lr=1e-4)
+        opt.zero_grad()
+        loss, parts = harness.training_step(m, xa, ya)
+        loss.backward()
+        grads = m._flat[1].clone()
+        opt.step()
+        torch.cuda.synchronize()
+        runs.append((parts["ord_label_pred"].detach().clone(), grads, m._flat[0].clone()))
+    (P0, g0, w0), (P1, g1, w1), (P2, g2, w2) = runs
+    assert torch.equal(P0, P1) and torch.equal(g0, g1) and torch.equal(w0, w1)
+    assert g0.abs().max() > 0
+    assert (P0 - P2).abs().max().item() < 5e-4          # two float32 summation orders (measured 1.8e-4: the probabilities amplify the 1e-5 logit noise)
+    assert ((g0 - g2).norm() / g0.norm()).item() < 5e-2    # ... and their ReLU-flip noise (measured 2.6e-2)
 
 
 def test_direct_gradient_mode_and_fused_adamw(dev):
