@@ -39,12 +39,12 @@ def main():
     # attainable peaks on THIS device (denominators next to the datasheet values)
     n = 1 << 28                                                     # 1 GiB each way
     a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
-    t = timeit(lambda: _lib.check(L0.rdm_microbench_copy(_lib.ptr(a), _lib.ptr(b), n, _lib.stream())), reps=10)
+    t = timeit(lambda: _lib.check(_lib.bench_lib().rdm_microbench_copy(_lib.ptr(a), _lib.ptr(b), n, _lib.stream())), reps=10)
     report("microbench: float4 stream copy 1 GiB -> 1 GiB", t, 2 * n * 4, "attainable HBM3E rate (read + write)")
     del a, b
     sc = torch.empty(4096, device=dev)
     blocks, iters = 256 * 4, 20000
-    t = timeit(lambda: _lib.check(L0.rdm_microbench_mfma_f32(_lib.ptr(sc), blocks, iters, _lib.stream())), reps=3)
+    t = timeit(lambda: _lib.check(_lib.bench_lib().rdm_microbench_mfma_f32(_lib.ptr(sc), blocks, iters, _lib.stream())), reps=3)
     tf = blocks * 4 * iters * 12 * 2048 / t / 1e12
     print(json.dumps({"kernel": "microbench: v_mfma_f32_16x16x4_f32 loop, 4 waves/SIMD, 12 accumulators", "ms": round(t * 1e3, 3),
                       "achieved_TFLOPs": round(tf, 1), "mfma_peak_TFLOPs": 157.3, "frac": round(tf / 157.3, 4),

@@ -74,21 +74,6 @@ void rdm_census_reset(void);
 int32_t rdm_census_count(void);
 int rdm_census_entry(int32_t i, const char** name, int64_t* launches);
 
-/* Attainable-peak microbenchmarks: float4 stream copy (HBM) and a register-only
- * v_mfma_f32_16x16x4_f32 loop (blocks x 4 waves x iters x 12 MFMAs of 2048 FLOP). */
-int rdm_microbench_copy(const float* src, float* dst, int64_t n_floats, rdm_stream_t stream);
-int rdm_microbench_mfma_f32(float* scratch, int32_t blocks, int32_t iters, rdm_stream_t stream);
-/* The conv kernels' 48-MFMA slab (4 x 3 tiles, distinct operands) as a loop with ONE staging ingredient added per mode: 0 registers only,
- * 1 + the slab's ds_read_b128 fragment reads, 2 + a workgroup barrier, 3 + flat-address LDS-DMA staging, 4 the A tile only, 5 issued but
- * never waited for, 6 buffer-form LDS-DMA from a window of span_floats (power of two) of `scratch` - L1-, L2-, Infinity-Cache- or
- * HBM-resident depending on the span.  FLOPs = blocks * 4 waves * slabs * 48 * 2048. */
-int rdm_microbench_mfma_staged_f32(float* scratch, int64_t scratch_floats, int32_t blocks, int32_t slabs, int32_t mode, int64_t span_floats,
-                                   rdm_stream_t stream);
-/* Pipeline experiment: f32 GEMM c[m][n] = sum_k a[m][k] * w[n][k] with LDS-DMA staging (global_load_lds_dwordx4) and
- * ds_read_b128 fragments, 128 x 96 tiles; k a multiple of 16; variant = LDS buffers (2 or 3). */
-int rdm_microbench_gemm_dma_f32(const float* a, int32_t lda, const float* w, int32_t ldw, float* c, int32_t ldc, int32_t m, int32_t n, int32_t k,
-                                int32_t variant, rdm_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM).  Replaces the nn.Conv2d / torchvision
  * _DenseLayer / _Transition convolutions of network/RDM_Net.py:144,146-147,524-531 and the WSM
@@ -251,8 +236,13 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *   RDM_NET_OPT_DETERMINISTIC    ordered reductions everywhere (for tests): no K split (so no f32 atomics with more than one contributor),
  *                                channel statistics and the dgrad gate / BatchNorm-backward sums as separate passes with a fixed summation
  *                                order, no layer pipelining.  Two runs on the same inputs then give bit-identical gradients; several
- *                                times slower than the default. */
-typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4 } rdm_net_option;
+ *                                times slower than the default.
+ *   RDM_NET_OPT_JOIN_PER_SEGMENT rdm_net_backward_stage orders the library's side stream (weight gradients) before the caller's stream at the
+ *                                end of each of the 4 SEGMENTS only, not after every stage: for callers that do not consume gradients
+ *                                stage by stage (no data-parallel exchange).  The gradients of a segment are complete on the caller's
+ *                                stream once its last stage has returned. */
+typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -34,10 +34,6 @@ _SIGNATURES = {
     "rdm_profile_kind_bytes": (f64, [i32]),
     "rdm_nyu_preprocess_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "rdm_nyu_preprocess": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    "rdm_microbench_copy": (C.c_int, [vp, vp, i64, vp]),
-    "rdm_microbench_mfma_f32": (C.c_int, [vp, i32, i32, vp]),
-    "rdm_microbench_mfma_staged_f32": (C.c_int, [vp, i64, i32, i32, i32, i64, vp]),
-    "rdm_microbench_gemm_dma_f32": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
@@ -108,7 +104,17 @@ _SIGNATURES = {
     "rdm_adamw_fused": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 
+# librdm_bench.so (include/rdm_bench.h): measurement kernels of tools/ and bench_ops.py - not part of the product
+_BENCH_SIGNATURES = {
+    "rdm_microbench_copy": (C.c_int, [vp, vp, i64, vp]),
+    "rdm_microbench_mfma_f32": (C.c_int, [vp, i32, i32, vp]),
+    "rdm_microbench_mfma_staged_f32": (C.c_int, [vp, i64, i32, i32, i32, i64, vp]),
+    "rdm_microbench_gemm_dma_f32": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+}
+BENCH_LIB_PATH = os.path.join(_HERE, "librdm_bench.so")
+
 _lib = None
+_bench = None
 
 
 class RdmError(RuntimeError):
@@ -141,8 +147,27 @@ def census():
     return out
 
 
+def bench_lib():
+    """librdm_bench.so, for development tools only (the product never loads it)."""
+    global _bench
+    if _bench is None:
+        lib()                                       # the bench library resolves its support symbols from the product library
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise RdmError(f"{BENCH_LIB_PATH} not found - run `python -m md_rdm_amd.build`")
+        B = C.CDLL(BENCH_LIB_PATH)
+        for name, (res, args) in _BENCH_SIGNATURES.items():
+            fn = getattr(B, name)
+            fn.restype, fn.argtypes = res, args
+        _bench = B
+    return _bench
+
+
 def exported_symbols():
     return list(_SIGNATURES)
+
+
+def bench_symbols():
+    return list(_BENCH_SIGNATURES)
 
 
 def check(rc):

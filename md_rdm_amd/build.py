@@ -8,6 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "librdm_hip.so")
+BENCH_SRC = os.path.join(CSRC, "bench")
+BENCH_LIB = os.path.join(HERE, "librdm_bench.so")           # measurement kernels of tools/ and bench_ops.py: not the product
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
@@ -64,6 +66,25 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"link failed:\n{r.stderr}")
         if verbose:
             print(f"[build] linked {LIB} ({mode})", flush=True)
+    # the development tools' measurement kernels: their own library next to the product, resolving set_error / the launch counter from it
+    bsrcs = sorted(f for f in os.listdir(BENCH_SRC) if f.endswith(".hip")) if os.path.isdir(BENCH_SRC) else []
+    bobjs = []
+    for src in bsrcs:
+        obj = os.path.join(OBJ, "bench_" + src[:-4] + ".o")
+        bobjs.append(obj)
+        if force or _stale(obj, [os.path.join(BENCH_SRC, src)] + headers + [os.path.join(HERE, "..", "include", "rdm_bench.h")]):
+            r = subprocess.run([hipcc] + flags + ["-c", os.path.join(BENCH_SRC, src), "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on bench/{src}:\n{r.stderr}")
+            if verbose:
+                print(f"[build] bench/{src}", flush=True)
+    if bobjs and (force or _stale(BENCH_LIB, bobjs + [LIB])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", BENCH_LIB] + bobjs + ["-L" + HERE, "-lrdm_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+        if verbose:
+            print(f"[build] linked {BENCH_LIB}", flush=True)
     with open(stamp, "w") as fh:
         fh.write(mode)
     return LIB

@@ -3,7 +3,8 @@
 // actually holds.  They give the "measured-attainable" denominators next to the datasheet peaks.
 #include <algorithm>
 
-#include "rdm_common.h"
+#include "../rdm_common.h"
+#include "../../../include/rdm_bench.h"
 
 namespace rdm {
 

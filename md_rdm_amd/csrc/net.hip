@@ -181,6 +181,7 @@ struct NetImpl {
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
+  int opt_join_seg = 0;        // RDM_NET_OPT_JOIN_PER_SEGMENT: the side stream joins the caller's stream at the end of each of the 4 segments only
   int opt_det = 0;             // RDM_NET_OPT_DETERMINISTIC: ordered reductions everywhere (tests), see DetScope
   int opt_no_wino = 0;         // RDM_NET_OPT_DIRECT_3X3: keep the direct implicit-GEMM kernels everywhere (A/B and tests)
   int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
@@ -487,7 +488,7 @@ int zero_f32(float* p, size_t n, hipStream_t s) {
   return 0;
 }
 
-int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
+int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
   const BlockGeom& g = n.bg[b];
   const int training = n.training_saved;
   float* blk = at<float>(ws, n.blk[b]);
@@ -577,10 +578,15 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, void* ws, void* const*
                                   Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
       return rc;
   }
-  // join: everything the side stream produced (weight gradients) is ordered before what the caller enqueues next
-  RDM_HIP_OK(hipEventRecord(n.ev_side, side));
-  RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
-  n.dz_busy[0] = n.dz_busy[1] = false;
+  // join: everything the side stream produced (weight gradients) is ordered before what the caller enqueues next.  A caller that
+  // consumes gradients stage by stage (the data-parallel exchange) needs it after every stage; without one it is needed once per
+  // segment only (RDM_NET_OPT_JOIN_PER_SEGMENT) and the dgrad chain of the next stage starts without draining the wgrad stream -
+  // the dZ double buffers stay fenced by their own events (dz_busy) across stages
+  if (join) {
+    RDM_HIP_OK(hipEventRecord(n.ev_side, side));
+    RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
+    n.dz_busy[0] = n.dz_busy[1] = false;
+  }
   return 0;
 }
 
@@ -663,6 +669,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_GRADS_PREZEROED) n->opt_prezeroed = value != 0;
   else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
+  else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }
@@ -961,7 +968,7 @@ static int backward_stage(NetImpl& n, int stage, const float* dlogits, void* ws,
     if (st.seg == 0) { if ((rc = backward_head(n, dlogits, ws, T, Gr, s))) return rc; }
     else if ((rc = backward_transition(n, st.block, ws, T, Gr, s))) return rc;          // seg 1 -> trans_e4 (t = 2) feeding dense_e4 (b = 2), ...
   }
-  if ((rc = backward_block(n, st.block, st.i_hi, st.i_lo, ws, T, Gr, s))) return rc;
+  if ((rc = backward_block(n, st.block, st.i_hi, st.i_lo, st.last_of_seg || !n.opt_join_seg, ws, T, Gr, s))) return rc;
   if (st.last_of_seg && st.seg == 3 && (rc = backward_stem(n, ws, T, Gr, s))) return rc;
   return 0;
 }

@@ -459,6 +459,8 @@ class DepthEstimationNet(BaseModel):
             gt.append(g.data_ptr() if g is not None else None)
         gtable = (C.c_void_p * len(gt))(*gt)
         st = _lib.stream()
+        # without a per-stage consumer (the data-parallel exchange) the side stream joins once per segment, not after each of the 13 stages
+        _lib.check(L.rdm_net_set_option(h, 5, 0 if self.grad_ready_hook is not None else 1))
         gflat.zero_()                                                # ONE fill instead of ~160 per-tensor fills inside the plan
         for stage in range(L.rdm_net_num_backward_stages()):        # ~25 MB of gradients per stage: the DP exchange starts every few layers
             _lib.check(L.rdm_net_backward_stage(h, _lib.ptr(dlogits), table, gtable, C.c_void_p(self._ws.data_ptr()), ws_bytes, stage, st))

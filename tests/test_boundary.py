@@ -30,6 +30,19 @@ def test_header_symbols_exported_and_bound(L):
         assert hasattr(L, name)
 
 
+def test_bench_library_is_separate_from_the_product(L):
+    """The measurement kernels live in librdm_bench.so (include/rdm_bench.h): declared == bound == exported THERE, and the product
+    library exports none of them."""
+    from md_rdm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rdm_bench.h")).read()
+    declared = set(re.findall(r"\b(rdm_microbench_[a-z0-9_]+)\s*\(", hdr))
+    assert declared and declared == set(_lib.bench_symbols())
+    B = _lib.bench_lib()
+    for name in declared:
+        assert hasattr(B, name) and not hasattr(L, name), name
+    assert "microbench" not in open(HEADER).read()
+
+
 def test_every_entry_point_cites_the_reference():
     hdr = open(HEADER).read()
     assert hdr.count("RDM_Net.py:") >= 6 and hdr.count("computations.py:") >= 8

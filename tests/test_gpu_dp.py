@@ -94,3 +94,26 @@ def test_two_rank_train_step_matches_single_process_with_averaged_gradients(tmp_
     np.testing.assert_allclose(r0["rm"], rm_after[0], rtol=1e-5, atol=1e-7)
     assert np.abs(rm_after[0] - rm_after[1]).max() > 1e-5
     assert int(r0["nbt"]) == 1
+
+
+def test_bench_two_ranks_prints_one_weak_scaling_json_line():
+    """The driver's N > 1 launch of bench.py, rehearsed at N = 2: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`
+    (one rank per GPU over RCCL when the box has two; on the one-GPU box both ranks share the card and exchange over gloo).  Rank 0 must
+    print exactly ONE JSON line: whole-job throughput over both ranks, weak scaling, the max-over-ranks step time, global batch = 2 x
+    the per-GPU batch; the extra single-GPU configurations and the CPU baseline stay out of a multi-rank run."""
+    import json
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = str(31200 + os.getpid() % 1500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--backend", backend]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]      # images of BOTH ranks / the slowest rank's time
+    assert d["cpu_baseline"] is None and "extra_configs" not in d
+    assert d["roofline"]["bound"] == "mfma" and np.isfinite(d["config"]["loss"])

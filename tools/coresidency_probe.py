@@ -24,7 +24,7 @@ def apply(stream):
     _lib.check(L.rdm_bn_bwd(_lib.ptr(dx), Cb, _lib.ptr(dz), Cb, _lib.ptr(x), Cb, _lib.ptr(s0), _lib.ptr(s1), float(M), _lib.ptr(g), _lib.ptr(mu), _lib.ptr(rs),
                             _lib.ptr(dg), _lib.ptr(db), M, Cb, 0, 1, C.c_void_p(stream.cuda_stream)))
 def copy(stream):
-    _lib.check(L.rdm_microbench_copy(_lib.ptr(dz), _lib.ptr(dx), M * Cb, C.c_void_p(stream.cuda_stream)))
+    _lib.check(_lib.bench_lib().rdm_microbench_copy(_lib.ptr(dz), _lib.ptr(dx), M * Cb, C.c_void_p(stream.cuda_stream)))
 
 main = torch.cuda.current_stream()
 def timed(fn, beside):

@@ -41,7 +41,7 @@ d3 = ConvDesc(B, H, W, Cb, Cb, 48, 48, 3, 3, 1, 1, 1, 1)
 big = torch.empty(300 * 2**20 // 4, device=dev)          # > 256 MiB streamed between dispatches: nothing of X survives in the Infinity Cache
 def flush(): big.fill_(1.0)
 for rep in range(2):
-    flush(); check(L.rdm_microbench_copy(ptr(Y), ptr(dZ), M * Cb, stream()))
+    flush(); check(_lib.bench_lib().rdm_microbench_copy(ptr(Y), ptr(dZ), M * Cb, stream()))
     flush(); check(L.rdm_conv2d_dgrad(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, None, 0, None, None, None, None, stream()))
     flush(); check(L.rdm_conv2d_dgrad(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), stream()))
 torch.cuda.synchronize()

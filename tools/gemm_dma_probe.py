@@ -37,12 +37,12 @@ for (B, H, W, N, K) in ((16, 29, 38, 1392, 704), (16, 29, 38, 1392, 384), (16, 5
     for v in (20, 32, 33, 34):
         if v == 40 and At is None: continue
         if v == 40:
-            new = lambda: check(L.rdm_microbench_gemm_dma_f32(ptr(At), K, ptr(Wtt), K, ptr(Cn), N, M, N, K, v, stream()))
+            new = lambda: check(_lib.bench_lib().rdm_microbench_gemm_dma_f32(ptr(At), K, ptr(Wtt), K, ptr(Cn), N, M, N, K, v, stream()))
             t1 = bench(new)
             err = (Cn - Cr).abs().max().item() / Cr.abs().max().item()
             line += f" | v{v} (pre-tiled operands): {t1*1e3:.3f} ms {fl/t1/1e12:.1f} TF ({fl/t1/1e12/157.3*100:.0f}%) relerr {err:.1e}"
             continue
-        new = lambda: check(L.rdm_microbench_gemm_dma_f32(ptr(A), K, ptr(Wt), K, ptr(Cn), N, M, N, K, v, stream()))
+        new = lambda: check(_lib.bench_lib().rdm_microbench_gemm_dma_f32(ptr(A), K, ptr(Wt), K, ptr(Cn), N, M, N, K, v, stream()))
         t1 = bench(new)
         err = (Cn - Cr).abs().max().item() / Cr.abs().max().item()
         line += f" | v{v}: {t1*1e3:.3f} ms {fl/t1/1e12:.1f} TF ({fl/t1/1e12/157.3*100:.0f}%) relerr {err:.1e}"

@@ -9,7 +9,7 @@ n = (1 << 29) + 16384                      # 2 GiB of floats + slack
 sc = torch.zeros(n, device="cuda")
 for blocks in (256 * 2, 256 * 4):
     for span in (1 << 14, 1 << 17, 1 << 19, 1 << 21, 1 << 23, 1 << 25, 1 << 27, 1 << 29):
-        run = lambda: _lib.check(L.rdm_microbench_mfma_staged_f32(_lib.ptr(sc), n, blocks, 4000, 6, span, _lib.stream()))
+        run = lambda: _lib.check(_lib.bench_lib().rdm_microbench_mfma_staged_f32(_lib.ptr(sc), n, blocks, 4000, 6, span, _lib.stream()))
         run(); torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(3): run()
