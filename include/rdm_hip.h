@@ -372,6 +372,13 @@ size_t rdm_als_workspace_bytes(int32_t groups, int32_t batch, int32_t rows, int3
 int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups, int32_t batch, int32_t rows, int32_t cols,
                   int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 
+/* The paged head in one call (RDM_Net.py:259-311 + computations.py:95-155 for every 16x16 page): rdm_ratio_grid_lloyd_paged fused INTO
+ * the ALS load - each ALS thread forms its own 64-entry row of the quantised grid from dn and the 3x3 window of dn_1, so the float64
+ * grid (134 MB at d_10, B = 16) is never written or read; p (P,B,256) float32 is bit-identical with rdm_ratio_grid_lloyd_paged ->
+ * rdm_als_rank1(r_is_f64 = 1).  Workspace: rdm_als_workspace_bytes((s/16)^2, batch, 256, 64, limit). */
+int rdm_als_rank1_paged(const float* dn, const double* dn_1, float* p_out, int32_t batch, int32_t s, const double* quant40, const double* inv41,
+                        int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+
 /* computations.py:201-216 split_matrix: (B,S,S) -> (P,B,page,page) row-major pages, P = (S/page)^2 */
 int rdm_page_split_f32(const float* src, float* pages, int32_t batch, int32_t s, int32_t page, rdm_stream_t stream);
 /* computations.py:218-238 reconstruct, bug-as-spec: out[b,y,x] = pages[y/page][b, y%page, x%page] */

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "rdm_ratio_grid_lloyd_paged": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "rdm_als_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "rdm_als_rank1": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "rdm_als_rank1_paged": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp, sz, vp]),
     "rdm_page_split_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "rdm_page_reconstruct_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "rdm_adamw_fused": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),

@@ -99,9 +99,17 @@ __device__ __forceinline__ float block_sum_f(float v, float* sh) {
 // serves k* <= keep from those, and the REPLAY pass - which exits at once otherwise - re-runs a matrix to k* for the rest.  The
 // reference's R' "reinterpretation" (computations.py:133) makes the rmse rise after the first update, so k* = 1 on real ratio
 // grids and the replay never reads a byte; a late arg-min costs one more pass over R (same operations, same order, same bits).
-template <int ROWS, bool F64IN, bool REPLAY>
-__global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, float* __restrict__ hist, double* __restrict__ sse, const int* __restrict__ kstar,
-                                              float* __restrict__ out, int batch, int limit, int keep) {
+// INK = what the matrix is read from: 0 a float32 grid, 1 a float64 grid (rdm_ratio_grid_lloyd_paged's output), 2 NOTHING - the thread
+// FORMS its row of the paged, Lloyd-quantised ratio grid itself (rdm_als_rank1_paged): row t of page (pi, pj) is the fine pixel
+// (t >> 4, t & 15) against the 8x8 coarse page, i.e. dn[pixel] * (1 / area) with area = 1 outside the 3x3 window at
+// clamp(r/2, 0, 5), clamp(c/2, 0, 5) (RDM_Net.py:259-284, computations.py:269-295) - 55 of the 64 entries are the SAME quantised value
+// and 9 come from the window, so the row costs 10 Lloyd look-ups and the 134 MB float64 grid of d_10 never exists in HBM.  The
+// arithmetic (float64 product, 40 float64 threshold compares, float64 level, one cast to float32) is the unfused path's, bit for bit.
+struct PagedSrc { const float* dn; const double* dn1; const double* quant; const double* inv; int S; };
+
+template <int ROWS, int INK, bool REPLAY>
+__global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, PagedSrc ps, float* __restrict__ hist, double* __restrict__ sse,
+                                              const int* __restrict__ kstar, float* __restrict__ out, int batch, int limit, int keep) {
   // One matrix per workgroup, one ROW per thread, the row held in 64 VGPRs for all iterations:
   // R is read from HBM exactly once and never re-read from LDS either; only the two vectors
   // (p: ROWS floats, q: 64 floats) live in LDS and are read as broadcasts.  Thread t's row is also
@@ -119,7 +127,30 @@ __global__ __launch_bounds__(ROWS) void k_als(const void* __restrict__ Rin, floa
     if (last <= keep) return;        // served from the recorded iterates (wave-uniform: the whole workgroup leaves)
   }
   float r[COLS];
-  if (F64IN) {
+  if (INK == 2) {
+    __shared__ double lq[40], liv[41];
+    if (t < 40) lq[t] = ps.quant[t];
+    if (t < 41) liv[t] = ps.inv[t];
+    __syncthreads();
+    const int ratio = ps.S / 16, S1 = ps.S / 2;
+    const int pi_ = group / ratio, pj_ = group - pi_ * ratio;
+    const int fr = t >> 4, fc = t & 15;
+    const int rs = min(max(fr >> 1, 0), 5), cs = min(max(fc >> 1, 0), 5);
+    const double v = (double)ps.dn[((long)b * ps.S + (16 * pi_ + fr)) * ps.S + 16 * pj_ + fc];
+    const float base = (float)liv[lloyd_index_f64(v * (1.0 / 1.0), lq)];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) r[j] = base;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double area = ps.dn1[((long)b * S1 + (8 * pi_ + rs + a)) * S1 + 8 * pj_ + cs + c];
+        const float w = (float)liv[lloyd_index_f64(v * (1.0 / area), lq)];
+        const int jw = (rs + a) * 8 + cs + c;
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) r[j] = (j == jw) ? w : r[j];
+      }
+  } else if (INK == 1) {
     const double2* src = reinterpret_cast<const double2*>(static_cast<const double*>(Rin) + (mat * ROWS + t) * COLS);
 #pragma unroll
     for (int j = 0; j < COLS / 2; ++j) { const double2 v = src[j]; r[2 * j] = (float)v.x; r[2 * j + 1] = (float)v.y; }
@@ -280,9 +311,10 @@ int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups,
   int* kstar = reinterpret_cast<int*>(w); w += ((size_t)groups * 4 + 255) & ~(size_t)255;
   float* rmse = reinterpret_cast<float*>(w);
   const int nmat = groups * batch, keep = als_keep(limit);
-#define RDM_ALS(ROWS_, F64_, REPLAY_) hipLaunchKernelGGL((k_als<ROWS_, F64_, REPLAY_>), dim3(nmat), dim3(ROWS_), 0, stream, R, hist, sse, kstar, p_out, batch, limit, keep)
-  if (rows == 256) { if (r_is_f64) RDM_ALS(256, true, false); else RDM_ALS(256, false, false); }
-  else { if (r_is_f64) RDM_ALS(64, true, false); else RDM_ALS(64, false, false); }
+  const PagedSrc ps{};
+#define RDM_ALS(ROWS_, F64_, REPLAY_) hipLaunchKernelGGL((k_als<ROWS_, F64_, REPLAY_>), dim3(nmat), dim3(ROWS_), 0, stream, R, ps, hist, sse, kstar, p_out, batch, limit, keep)
+  if (rows == 256) { if (r_is_f64) RDM_ALS(256, 1, false); else RDM_ALS(256, 0, false); }
+  else { if (r_is_f64) RDM_ALS(64, 1, false); else RDM_ALS(64, 0, false); }
   RDM_LAUNCH_OK();
   hipLaunchKernelGGL(k_als_select, dim3(groups), dim3(64), 0, stream, sse, kstar, rmse, batch, limit, (double)batch * rows * cols);
   RDM_LAUNCH_OK();
@@ -290,11 +322,39 @@ int rdm_als_rank1(const void* R, int32_t r_is_f64, float* p_out, int32_t groups,
   else hipLaunchKernelGGL((k_als_finish<64>), dim3(nmat), dim3(64), 0, stream, hist, kstar, p_out, batch, keep);
   RDM_LAUNCH_OK();
   if (limit > keep) {                                        // groups whose arg-min lies past the recorded iterates (exits at once otherwise)
-    if (rows == 256) { if (r_is_f64) RDM_ALS(256, true, true); else RDM_ALS(256, false, true); }
-    else { if (r_is_f64) RDM_ALS(64, true, true); else RDM_ALS(64, false, true); }
+    if (rows == 256) { if (r_is_f64) RDM_ALS(256, 1, true); else RDM_ALS(256, 0, true); }
+    else { if (r_is_f64) RDM_ALS(64, 1, true); else RDM_ALS(64, 0, true); }
     RDM_LAUNCH_OK();
   }
 #undef RDM_ALS
+  return RDM_OK;
+}
+
+int rdm_als_rank1_paged(const float* dn, const double* dn_1, float* p_out, int32_t batch, int32_t s, const double* quant40, const double* inv41,
+                        int32_t limit, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(dn && dn_1 && p_out && quant40 && inv41 && workspace && batch > 0 && limit >= 0, "als_rank1_paged: bad argument");
+  RDM_CHECK_ARG(s >= 16 && s % 16 == 0 && s <= 1024, "als_rank1_paged: side (%d) must be a multiple of 16", s);
+  const int groups = (s / 16) * (s / 16), rows = 256;
+  const size_t need = rdm_als_workspace_bytes(groups, batch, rows, 64, limit);
+  if (workspace_bytes < need) { set_error("als_rank1_paged: workspace too small: %zu < %zu", workspace_bytes, need); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "als_rank1_paged: workspace must be 256-byte aligned");
+  char* w = static_cast<char*>(workspace);
+  float* hist = reinterpret_cast<float*>(w); w += als_hist_bytes(groups, batch, rows, limit);
+  double* sse = reinterpret_cast<double*>(w); w += als_sse_bytes(groups, batch, limit);
+  int* kstar = reinterpret_cast<int*>(w); w += ((size_t)groups * 4 + 255) & ~(size_t)255;
+  float* rmse = reinterpret_cast<float*>(w);
+  const int nmat = groups * batch, keep = als_keep(limit);
+  const PagedSrc ps{dn, dn_1, quant40, inv41, s};
+  hipLaunchKernelGGL((k_als<256, 2, false>), dim3(nmat), dim3(256), 0, stream, nullptr, ps, hist, sse, kstar, p_out, batch, limit, keep);
+  RDM_LAUNCH_OK();
+  hipLaunchKernelGGL(k_als_select, dim3(groups), dim3(64), 0, stream, sse, kstar, rmse, batch, limit, (double)batch * rows * 64);
+  RDM_LAUNCH_OK();
+  hipLaunchKernelGGL((k_als_finish<256>), dim3(nmat), dim3(256), 0, stream, hist, kstar, p_out, batch, keep);
+  RDM_LAUNCH_OK();
+  if (limit > keep) {
+    hipLaunchKernelGGL((k_als<256, 2, true>), dim3(nmat), dim3(256), 0, stream, nullptr, ps, hist, sse, kstar, p_out, batch, limit, keep);
+    RDM_LAUNCH_OK();
+  }
   return RDM_OK;
 }
 

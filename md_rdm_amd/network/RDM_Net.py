@@ -141,8 +141,7 @@ class Ordinal_Layer(nn.Module):
         dn = x
         dn_1 = cp.resize(dn, self.quant.get_size_id(self.id - 1))
         q, inv = self.quant.device_tables(self.id, dn.device)
-        R = cp.ratio_grid_lloyd_paged(dn, dn_1, q, inv)                      # (P,B,256,64) f64
-        pages = cp.als_pages(R, limit=100)                                   # (P,B,1,16,16) f32
+        pages = cp.als_pages_fused(dn, dn_1, q, inv, limit=100)              # (P,B,1,16,16) f32: grid + Lloyd formed inside the ALS load
         if self.id == 4:                                                     # d_7: single page
             return pages[0]
         return cp.reconstruct(list(pages))                                   # d_8..d_10

@@ -339,6 +339,22 @@ def als_pages(R, limit=100):
     return _als(R, P, B, 256, 64, limit).view(P, B, 1, 16, 16)
 
 
+def als_pages_fused(dn, dn_1, quant, inv, limit=100):
+    """ratio_grid_lloyd_paged + als_pages in one call (rdm_als_rank1_paged): every ALS thread forms its row of the quantised grid from
+    dn and the 3x3 window of dn_1 - the (P,B,256,64) float64 grid never exists in HBM.  Bit-identical with the two-step path."""
+    _need_gpu(dn)
+    L = _lib.lib()
+    B, _, S, _ = dn.shape
+    a = dn.float().contiguous()
+    b = dn_1.to(_f64).contiguous()
+    P = (S // 16) ** 2
+    nbytes = int(L.rdm_als_workspace_bytes(P, B, 256, 64, limit))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    p = torch.empty(P, B, 256, dtype=torch.float32, device=a.device)
+    _lib.check(L.rdm_als_rank1_paged(_lib.ptr(a), _lib.ptr(b), _lib.ptr(p), B, S, _lib.ptr(quant), _lib.ptr(inv), limit, C.c_void_p(ws.data_ptr()), nbytes, _lib.stream()))
+    return p.view(P, B, 1, 16, 16)
+
+
 def alternating_least_squares(sparse_m, n, cuda, limit=30, debug=False):
     """computations.py:95-155."""
     _need_gpu(sparse_m)

@@ -209,6 +209,24 @@ def test_ratio_grids(env, op_gold):
         np.testing.assert_array_equal(Rp[p], want)
 
 
+@pytest.mark.parametrize("S,B,lim", [(16, 2, 100), (32, 3, 100), (128, 2, 100), (64, 2, 3)])
+def test_als_paged_fused_is_bit_identical_with_grid_then_als(env, S, B, lim):
+    """rdm_als_rank1_paged (the ratio grid + Lloyd quantisation formed INSIDE the ALS load: no float64 grid in HBM) against the
+    standalone operators rdm_ratio_grid_lloyd_paged -> rdm_als_rank1 it replaces in Ordinal_Layer.forward (RDM_Net.py:259-311,
+    computations.py:95-155): the same float64 products, threshold compares and levels, so the pages must agree BIT FOR BIT -
+    d_7 (one page), d_8 (4 pages, window clamping at the page edges), d_10 (64 pages), and a short iteration limit."""
+    cp, RDM = env["cp"], env["RDM"]
+    quant = RDM.Quantization()
+    tid = {16: 4, 32: 5, 64: 6, 128: 7}[S]
+    q, inv = quant.device_tables(tid, env["dev"])
+    dn = g(LU(f"op.fused{S}", (B, 1, S, S), 0.5, 2.0), env)
+    dn1 = cp.resize(dn, S // 2)
+    two = cp.als_pages(cp.ratio_grid_lloyd_paged(dn, dn1, q, inv), limit=lim)
+    one = cp.als_pages_fused(dn, dn1, q, inv, limit=lim)
+    assert one.shape == two.shape == ((S // 16) ** 2, B, 1, 16, 16)
+    assert torch.equal(one, two)
+
+
 @pytest.mark.parametrize("lim", [1, 5, 30, 100])
 def test_als_generic(env, op_gold, lim):
     R = LU("op.alsR", (3, 256, 64), 0.5, 2.0)
