@@ -62,7 +62,6 @@ def main():
     comp = Rf.numel() * 4 + 1024 * 256 * 4
     report("als_rank1 d_10 B=16 (1024 matrices, 100 iters) - compulsory bytes", t, comp,
            "R read once (register-resident), p written; two passes: squared errors + the first 8 iterates recorded (8 MB instead of the 106 MB full history), a late arg-min is replayed")
-    report("als_rank1 d_10 B=16 - streaming model of the reference algorithm", t, 301 * 65536 * 1024, "3 passes over R per iteration + 1 (SURVEY 8(d)): the reference's own traffic, never issued here")
     t = timeit(lambda: cp.als_pages(R, limit=100), reps=10)
     report("als_rank1 d_10 B=16, float64 grid input", t, R.numel() * 8 + 1024 * 256 * 4, "the standalone operator on the f64 grid (f64 -> f32 at load)")
     t = timeit(lambda: cp.als_pages_fused(dn, dn1, q, inv, limit=100), reps=10)
