@@ -215,10 +215,9 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
                 tj = json.load(fh)
             fam_traffic = tj["conv_kernels"]["bytes_per_launch"]
             key = dom["kernel"].split(" ")[0]
-            for e in tj.get("per_kernel", []):
-                if key in e["kernel"]:
-                    traffic = round((2 * e["fetch_raw_bytes_per_step"] + e["write_bytes_per_step"]) / e["launches_per_step"])
-                    break
+            fam = [e for e in tj.get("per_kernel", []) if key in e["kernel"] and (("taps" in dom["kernel"]) == ("true>" in e["kernel"]) or "wgrad_kernel" not in key)]
+            if fam:       # HBM-side bytes per launch, averaged over every instantiation of the dominant kernel family in the step
+                traffic = round(sum(2 * e["fetch_raw_bytes_per_step"] + e["write_bytes_per_step"] for e in fam) / sum(e["launches_per_step"] for e in fam))
             traffic_src = ("profiles/" + os.path.basename(tpath) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 "
                            "correction, checked on k_adamw), bytes per launch of this kernel averaged over one step")
         step_frac = algo / args.steps / (elapsed / args.steps) / 1e12 / peak

@@ -33,9 +33,9 @@ def main():
     n_params = 90529721
     kernels = []
     for k in sorted(fetch, key=lambda k: -fetch[k][1]):
-        kernels.append({"kernel": k.split("(")[0].replace("void ", ""), "launches_per_step": round(fetch[k][0] / steps, 2),
+        kernels.append({"kernel": k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), "launches_per_step": round(fetch[k][0] / steps, 2),
                         "fetch_raw_bytes_per_step": round(fetch[k][1] / steps), "write_bytes_per_step": round(write.get(k, [0, 0.0])[1] / steps)})
-    conv = [k for k in kernels if "conv_" in k["kernel"] or "conv3x3" in k["kernel"]]
+    conv = [k for k in kernels if "conv_" in k["kernel"] or "conv3x3" in k["kernel"] or "conv1x1" in k["kernel"]]
     adam = [k for k in kernels if "k_adamw" in k["kernel"]][0]
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, batch 16, 228x304",
