@@ -174,7 +174,7 @@ struct NetImpl {
   }
   // Winograd F(2x2, 3x3) for the 3x3 convs of the blocks with many pixels (wino.hip): transformed weights per layer (formed on the side
   // stream at the start of forward) and one scratch for the per-split partial outputs
-  bool wino_fwd[4] = {false, false, false, false};
+  bool wino_fwd[4] = {false, false, false, false}, wino_wg[4] = {false, false, false, false};
   int wino_split[4] = {1, 1, 1, 1};
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
@@ -280,9 +280,11 @@ struct NetImpl {
     logits = a.take<float>((size_t)bg[3].M * 192);
     w2pad = a.take<float>((size_t)192 * 2208);
     for (int b = 0; b < 4; ++b) {
-      // Winograd where the 2.25x fewer MFMAs outweigh the transforms: >= 16 K pixels (dense_e2 / dense_e3 at the headline geometry;
-      // measured at 4 560 pixels it loses to the direct kernel, 0.052 vs 0.045 ms)
-      wino_fwd[b] = bg[b].M >= 16384 && bg[b].cb % 16 == 0;
+      // Winograd where the 2.25x fewer MFMAs outweigh the transforms (tools/wino_bench.py, Cb = 720): forward 0.061 vs 0.078 ms direct at
+      // 9 120 pixels, 0.087 vs 0.106 at 13 376 (KITTI's dense_e4), but 0.052 vs 0.044 at 4 560 (NYU's dense_e4); the weight gradient
+      // ties at 9 120 (0.103 vs 0.100) and wins from 13 376 (0.113 vs 0.136).  dense_e2 / dense_e3 of the headline geometry: 1.5-1.65x.
+      wino_fwd[b] = bg[b].M >= 8192 && bg[b].cb % 16 == 0;
+      wino_wg[b] = bg[b].M >= 12288 && bg[b].cb % 16 == 0;
       if (!wino_fwd[b]) continue;
       const int T = B * ((bg[b].H + 1) / 2) * ((bg[b].W + 1) / 2);
       wino_split[b] = wino_pick_split(T, bg[b].cb / 16);
@@ -292,7 +294,7 @@ struct NetImpl {
     }
     winoPartial = a.take<float>(winoPartialFloats);
     for (int b = 0; b < 4; ++b)
-      if (wino_fwd[b]) {
+      if (wino_wg[b]) {
         winoVyFloats = std::max(winoVyFloats, wino_wgrad_vy_floats(B, bg[b].H, bg[b].W));
         winoQFloats = std::max(winoQFloats, wino_wgrad_part_floats(B, bg[b].H, bg[b].W, bg[b].cb));
       }
@@ -515,7 +517,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       // packed gradients go straight to the caller's tensor; otherwise into a scratch that is unpacked to OIHW afterwards
       float* dW3 = n.opt_packed3x3 ? F(Gr, L.conv2) : at<float>(ws, W.dw3);
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_go, 0));
-      if (n.wino_fwd[b] && !n.opt_no_wino) {
+      if (n.wino_wg[b] && !n.opt_no_wino) {
         // Winograd F(3x3, 2x2): writes the gradient (ordered split reduction, no atomics, no zero fill)
         WinoWgrad wv{};
         wv.G = go; wv.ldg = g.ctot; wv.N = GROWTH; wv.A = Y; wv.lda = cb; wv.C = cb; wv.a_scale = bn2; wv.a_shift = bn2 + cb;

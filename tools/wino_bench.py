@@ -13,6 +13,8 @@ splits = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
 shapes = [(16, 57, 76, 2736), (16, 29, 38, 1392), (16, 15, 19, 720)]
 if len(sys.argv) > 2:
     shapes = shapes[:int(sys.argv[2])]
+if os.environ.get("SHAPES"):                          # e.g. SHAPES=8,22,76,720;8,44,152,1392
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for (B, H, W, Cb) in shapes:
     M = B * H * W
     y = torch.randn(M, Cb, device=dev); w = torch.randn(9, 48, Cb, device=dev) / (9 * Cb) ** 0.5
