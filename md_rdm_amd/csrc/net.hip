@@ -554,6 +554,8 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
+      // (round 3: moving this launch to the caller's stream for the last 1-4 layers of dense_e2 / e3 - where the side stream has become the
+      // longer one, 25.9 vs 22.3 ms of kernel time - changed nothing: 72.0-72.7 vs 72.2 ms; the step is throughput-bound, not balance-bound)
       RDM_HIP_OK(hipEventRecord(n.ev_dy, s));
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_dy, 0));
       if (!n.opt_prezeroed && (rc = zero_f32(F(Gr, L.conv1), (size_t)cb * cin, side))) return rc;
