@@ -369,6 +369,43 @@ def test_full_size_properties_b16_228x304(dev):
     assert dict(m.named_parameters())["encoder.conv_e1.weight"].grad.abs().max() > 0
 
 
+def test_kitti_train_step_b2_352x1216_vs_oracle(dev):
+    """BASELINE configs[4]'s geometry (352x1216: 88x304 / 44x152 / 22x76 / 11x38 maps; the Winograd kernels at 53 504 and 13 376 pixels, the
+    direct ones below) as a train step against the CPU oracle at B=2: block taps 1e-4, probabilities 2e-4, ordinal indices equal wherever the
+    oracle's pair decision has the margin, the ordinal loss 1e-4, every gradient tensor to the ReLU-flip noise level of a float32 evaluation
+    (relative L2 <= 4e-2 against the oracle's float32 gradients, their norms within 2e-2)."""
+    from md_rdm_amd import harness
+    B, H, W = 2, 352, 1216
+    x, y = filler.synthetic_batch(B, H, W, seed=4321)
+    m = make_model(dev)
+    loss, parts = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    taps = {}
+    r32 = onet.training_step(onet.new_state_dict(filler.state_value), torch.from_numpy(x), y, taps=taps)
+    for tap, (buf, c) in TAPS.items():
+        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
+        np.testing.assert_allclose(stats3(m.debug_buffer(buf).view(-1, ctot)[:, :c]), taps[tap], rtol=1e-4, atol=1e-6, err_msg=tap)
+    P = parts["ord_label_pred"].detach().cpu().numpy()
+    assert P.shape == (B, 90, 11, 38)
+    np.testing.assert_allclose(P, r32["P"], atol=2e-4)
+    safe = filler.dorn_safe_mask(r32["logits"])
+    np.testing.assert_array_equal(((P > 0.5) & safe).sum(1, keepdims=True), ((r32["P"] > 0.5) & safe).sum(1, keepdims=True))
+    np.testing.assert_allclose(parts["ord_loss"].item(), r32["ord_loss"], rtol=1e-4)
+    worst = (0.0, "")
+    for n, p in m.named_parameters():
+        g32 = r32["grads"].get(n)
+        if g32 is None or n.startswith("weight_layer."):
+            continue
+        g = p.grad.cpu().double()
+        g32 = g32.double()
+        e = ((g - g32).norm() / (g32.norm() + 1e-300)).item()
+        worst = max(worst, (e, n))
+        assert e < 4e-2, (n, e)
+        assert abs(g.norm().item() - g32.norm().item()) <= 2e-2 * g32.norm().item() + 1e-12, n
+    print("[kitti b2] worst gradient L2 vs the float32 oracle: %.3e (%s)" % worst)
+
+
 def test_kitti_geometry_b8_352x1216(dev):
     """BASELINE config 5 (wide aspect, 11x38 head; the reference's own forward raises past the DORN head there): same
     size-independent properties, plus the 38-wide maps exercise the 256-pixel halo tiles with a 6-load halo run."""
