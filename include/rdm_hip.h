@@ -290,6 +290,11 @@ int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, 
 double rdm_net_forward_flops(const rdm_net* net);
 double rdm_net_backward_flops(const rdm_net* net);
 
+/* Layout changes at the edges of the NHWC conv stack (the reference's tensors are NCHW: RDM_Net.py:70-135): src (B,C,HW) -> dst (B,HW,dst_ld)
+ * channel prefix, and back.  Used by the relative decoders d_6..d_10, which enter the stack with the encoder output. */
+int rdm_layout_nchw_to_nhwc_f32(const float* src, float* dst, int32_t dst_ld, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream);
+int rdm_layout_nhwc_to_nchw_f32(const float* src, int32_t src_ld, float* dst, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DORN ordinal head + ordinal loss.  RDM_Net.py:313-345 (DornOrdinalRegression), loss.py:8-59.
  * ------------------------------------------------------------------------------------------ */
@@ -320,6 +325,12 @@ int rdm_decompose_f64(const double* dn, double* levels, int32_t batch, int32_t n
 int rdm_fine_detail_pred_f32(const double* levels, const float* w, float* yhat, int32_t batch, int32_t n_levels, rdm_stream_t stream);
 /* dw[k] = sum dyhat_k * float32(log levels_k)   (gradient of the 4 Weights scalars, RDM_Net.py:443-491) */
 int rdm_fine_detail_pred_bwd(const double* levels, const float* dyhat, float* dw, int32_t batch, int32_t n_levels, rdm_stream_t stream);
+/* computations.py:512-528 make_pred with several candidates per level (the relative decoders add rows to the matrix of a level,
+ * RDM_Net.py:126-133): out[b][m] = sum_k float32(a[b][k][m]) * w[k], a (B,K,M) float64 (the log matrix), K <= 8; and the gradient of
+ * the weights dw[k] = sum_{b,m} dout[b][m] * float32(a[b][k][m]). */
+int rdm_candidates_matvec_f32(const double* a, const float* w, float* out, int32_t batch, int32_t k, int64_t m, rdm_stream_t stream);
+int rdm_candidates_matvec_bwd(const double* a, const float* dout, float* dw, int32_t batch, int32_t k, int64_t m, rdm_stream_t stream);
+
 /* computations.py:394-421 recombination: out (B,2^n_out,2^n_out) f64 = sum_{k>=first_level} nearest_up(yhat_k),
  * first_level = 0 when the list starts with d_0 (1x1), 1 for relative-only lists */
 int rdm_recombine_f64(const float* yhat, double* out, int32_t batch, int32_t n_levels, int32_t n_out, int32_t first_level, rdm_stream_t stream);

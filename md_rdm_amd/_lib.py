@@ -92,6 +92,10 @@ _SIGNATURES = {
     "rdm_decompose_f64": (C.c_int, [vp, vp, i32, i32, vp]),
     "rdm_fine_detail_pred_f32": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "rdm_fine_detail_pred_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+    "rdm_candidates_matvec_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
+    "rdm_candidates_matvec_bwd": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
+    "rdm_layout_nchw_to_nhwc_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "rdm_layout_nhwc_to_nchw_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, vp]),
     "rdm_recombine_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "rdm_recombine_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "rdm_depth_metrics_f64": (C.c_int, [vp, vp, i64, vp, vp]),

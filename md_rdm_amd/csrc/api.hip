@@ -384,6 +384,16 @@ int rdm_padavgpool2_bwd(const float* dpooled, const float* x, int32_t x_ld, cons
   return launch_trans_pool_bwd_apply(dpooled, x, x_ld, scale, shift, cA, cB, cC, dx, dx_ld, batch, h, w, channels, stream);
 }
 
+int rdm_layout_nchw_to_nhwc_f32(const float* src, float* dst, int32_t dst_ld, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && dst && batch > 0 && channels > 0 && hw > 0 && dst_ld >= channels, "layout_nchw_to_nhwc: bad argument");
+  return launch_nchw_to_nhwc(src, dst, dst_ld, batch, channels, hw, stream);
+}
+
+int rdm_layout_nhwc_to_nchw_f32(const float* src, int32_t src_ld, float* dst, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && dst && batch > 0 && channels > 0 && hw > 0 && src_ld >= channels, "layout_nhwc_to_nchw: bad argument");
+  return launch_nhwc_to_nchw(src, src_ld, dst, batch, channels, hw, stream);
+}
+
 int rdm_adamw_fused(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float grad_scale, rdm_stream_t stream) {
   RDM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adamw_fused: bad argument");

@@ -1058,7 +1058,7 @@ int pick_split_k(long tiles, long kslabs, int slots) {
   // (MINS, LO, HI) = (16, 1, 3): swept on one MI355X over the B=16 228x304 step - (8, 2, 5) was 7 % slower
   // (too many short splits on the M=4560 / M=1280 layers), 32 slabs 4 % slower, 64 slabs 16 % slower
   constexpr int MINS = 16;
-  constexpr double LO = 1.0, HI = 3.0;
+  constexpr double LO = 1.0, HI = 3.0;      // re-swept in round 3 with the Winograd kernels in place (LO 0.6-0.85, HI 2-3): 71.9-72.6 ms, no change
   if (tiles >= 6L * slots) return 1;
   long cap = kslabs / MINS;
   if (cap < 1) cap = 1;

@@ -152,6 +152,30 @@ __global__ __launch_bounds__(256) void k_fine_detail_pred_bwd(const double* __re
   if (threadIdx.x == 0) dw[k] = (float)r;
 }
 
+// multi-candidate make_pred (computations.py:512-528): out[b][m] = sum_k float32(A[b][k][m]) * w[k]   (A^T.float() @ w.float(), K <= 8 candidates)
+__global__ void k_candidates_matvec(const double* __restrict__ A, const float* __restrict__ w, float* __restrict__ out, int batch, int K, long M) {
+  const long total = (long)batch * M;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / M, m = i - b * M;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf((float)A[(b * K + k) * M + m], w[k], acc);
+    out[i] = acc;
+  }
+}
+
+// dw[k] = sum_{b,m} dout[b][m] * float32(A[b][k][m]); one workgroup per candidate
+__global__ __launch_bounds__(256) void k_candidates_matvec_bwd(const double* __restrict__ A, const float* __restrict__ dout, float* __restrict__ dw, int batch, int K, long M) {
+  __shared__ double sh[4];
+  const int k = blockIdx.x;
+  double acc = 0;
+  for (long i = threadIdx.x; i < (long)batch * M; i += 256) {
+    const long b = i / M, m = i - b * M;
+    acc += (double)dout[i] * (double)(float)A[(b * K + k) * M + m];
+  }
+  const double r = block_sum_bcast(acc, sh);
+  if (threadIdx.x == 0) dw[k] = (float)r;
+}
+
 __global__ void k_recombine(const float* __restrict__ yhat, double* __restrict__ out, int batch, int n_levels, int n_out, int first_level) {
   const int S = 1 << n_out;
   const long per = level_off(n_levels);
@@ -239,6 +263,20 @@ int rdm_fine_detail_pred_f32(const double* levels, const float* w, float* yhat, 
 int rdm_fine_detail_pred_bwd(const double* levels, const float* dyhat, float* dw, int32_t batch, int32_t n_levels, rdm_stream_t stream) {
   RDM_CHECK_ARG(levels && dyhat && dw && batch > 0 && n_levels >= 1 && n_levels <= 8, "fine_detail_pred_bwd: bad argument");
   hipLaunchKernelGGL(k_fine_detail_pred_bwd, dim3(n_levels), dim3(256), 0, stream, levels, dyhat, dw, batch, n_levels);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_candidates_matvec_f32(const double* a, const float* w, float* out, int32_t batch, int32_t k, int64_t m, rdm_stream_t stream) {
+  RDM_CHECK_ARG(a && w && out && batch > 0 && k >= 1 && k <= 8 && m > 0, "candidates_matvec: bad argument");
+  hipLaunchKernelGGL(k_candidates_matvec, dim3((int)std::min<long>(cdiv((long)batch * m, 256), 2048)), dim3(256), 0, stream, a, w, out, batch, k, (long)m);
+  RDM_LAUNCH_OK();
+  return RDM_OK;
+}
+
+int rdm_candidates_matvec_bwd(const double* a, const float* dout, float* dw, int32_t batch, int32_t k, int64_t m, rdm_stream_t stream) {
+  RDM_CHECK_ARG(a && dout && dw && batch > 0 && k >= 1 && k <= 8 && m > 0, "candidates_matvec_bwd: bad argument");
+  hipLaunchKernelGGL(k_candidates_matvec_bwd, dim3(k), dim3(256), 0, stream, a, dout, dw, batch, k, (long)m);
   RDM_LAUNCH_OK();
   return RDM_OK;
 }

@@ -157,27 +157,23 @@ def _make_wsm_layers_(num_of_layers):
 
 
 def _bn_affine(bn, s, q, count, training):
-    """BatchNorm as the per-channel (scale, shift) the conv prologue applies; training mode uses the batch statistics
+    """BatchNorm as the per-channel (scale, shift) the conv prologue applies (rdm_bn_finalize): training mode uses the batch statistics
     (f64 sums from the producing kernel) and updates the running statistics like nn.BatchNorm2d."""
-    if training:
-        mean = s / count
-        var = (q / count - mean * mean).clamp_(min=0.0)
-        with torch.no_grad():
-            m = bn.momentum
-            bn.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
-            bn.running_var.mul_(1 - m).add_((var * (count / max(count - 1, 1))).float(), alpha=m)
-            bn.num_batches_tracked += 1
-    else:
-        mean, var = bn.running_mean.double(), bn.running_var.double()
-    scale = bn.weight.double() / torch.sqrt(var + bn.eps)
-    return scale.float().contiguous(), (bn.bias.double() - mean * scale).float().contiguous()
+    L = _lib.lib()
+    c = bn.weight.numel()
+    out = torch.empty(4, c, dtype=torch.float32, device=bn.weight.device)        # scale | shift | mean | rstd
+    _lib.check(L.rdm_bn_finalize(_lib.ptr(s) if training else None, _lib.ptr(q) if training else None, float(count), _lib.ptr(bn.weight.detach()),
+                                 _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(bn.num_batches_tracked),
+                                 _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]), c, int(training), _lib.stream()))
+    return out[0], out[1]
 
 
 def _dense_block_forward(block, x, training):
     """torchvision ``_DenseBlock`` forward (RDM_Net.py:144) for the relative decoders, inference through the C ABI:
     one NHWC buffer holds all channels (concat-free), every conv is ``rdm_conv2d_fwd`` with the consumer's BN-ReLU as
-    prologue and the next BatchNorm's channel statistics as epilogue.  No autograd (the reference's Lloyd step severs
-    the graph above these decoders anyway, RDM_Net.py:296-297).  x (B,C,H,W) -> (B,H,W,C + 48*layers) NHWC."""
+    prologue and the next BatchNorm's channel statistics as epilogue; layout change, input statistics and the BatchNorm
+    bookkeeping are C-ABI calls too (rdm_layout_nchw_to_nhwc_f32, rdm_bn_stats, rdm_bn_finalize).  No autograd (the reference's
+    Lloyd step severs the graph above these decoders anyway, RDM_Net.py:296-297).  x (B,C,H,W) -> (B,H,W,C + 48*layers) NHWC."""
     from . import wsm as _wsm
     L = _lib.lib()
     B, cin0, H, W = x.shape
@@ -186,17 +182,15 @@ def _dense_block_forward(block, x, training):
     ctot = cin0 + GROWTH * len(layers)
     M = B * H * W
     dev = x.device
+    st = _lib.stream()
     blk = torch.zeros(B, H, W, ctot, dtype=torch.float32, device=dev)
-    blk[..., :cin0] = x.permute(0, 2, 3, 1)
+    _lib.check(L.rdm_layout_nchw_to_nhwc_f32(_lib.ptr(x.contiguous()), _lib.ptr(blk), ctot, B, cin0, H * W, st))
     ssum = torch.zeros(ctot, dtype=torch.float64, device=dev)
     ssq = torch.zeros(ctot, dtype=torch.float64, device=dev)
-    x64 = blk.view(M, ctot)[:, :cin0].double()
-    ssum[:cin0] = x64.sum(0)
-    ssq[:cin0] = (x64 * x64).sum(0)
+    _lib.check(L.rdm_bn_stats(_lib.ptr(blk), ctot, M, cin0, _lib.ptr(ssum), _lib.ptr(ssq), st))
     Y = torch.empty(M, cb, dtype=torch.float32, device=dev)
     ysum = torch.zeros(cb, dtype=torch.float64, device=dev)
     ysq = torch.zeros(cb, dtype=torch.float64, device=dev)
-    st = _lib.stream()
     for i, lay in enumerate(layers):
         cin = cin0 + i * GROWTH
         sc1, sh1 = _bn_affine(lay.norm1, ssum[:cin], ssq[:cin], M, training)

@@ -200,6 +200,30 @@ class _FineDetailPred(torch.autograd.Function):
         return (None, None) + tuple(dw[i].reshape(s) for i, s in enumerate(ctx.shapes))
 
 
+class _CandidatesMatvec(torch.autograd.Function):
+    """out[b][m] = sum_k float32(A[b][k][m]) * w[k] (the reference's A^T.float() @ w.float() for a level with several candidates);
+    gradient only w.r.t. the weights, as in the reference graph (the matrices are detached logs)."""
+
+    @staticmethod
+    def forward(ctx, A, w):
+        B, K, M = A.shape
+        A = A.to(_f64).contiguous()
+        wv = w.reshape(-1).float().contiguous()
+        out = torch.empty(B, M, dtype=torch.float32, device=A.device)
+        _lib.check(_lib.lib().rdm_candidates_matvec_f32(_lib.ptr(A), _lib.ptr(wv), _lib.ptr(out), B, K, M, _lib.stream()))
+        ctx.save_for_backward(A)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (A,) = ctx.saved_tensors
+        B, K, M = A.shape
+        dw = torch.empty(K, dtype=torch.float32, device=A.device)
+        _lib.check(_lib.lib().rdm_candidates_matvec_bwd(_lib.ptr(A), _lib.ptr(dout.contiguous().float()), _lib.ptr(dw), B, K, M, _lib.stream()))
+        return None, dw.reshape(ctx.wshape)
+
+
 def make_pred(w, A, cuda, relative_only):
     """computations.py:512-528 (mutates and returns ``A`` like the reference).  One weight per level
     on a packed pyramid -> single fused launch; otherwise the general per-level matvec."""
@@ -214,7 +238,10 @@ def make_pred(w, A, cuda, relative_only):
     for i in range(len(A)):
         B, M = A[i].shape[0], A[i].shape[2]
         s = int(math.sqrt(M))
-        A[i] = torch.matmul(A[i].transpose(1, 2).float(), weights[i].float()).view(B, 1, s, s)
+        if A[i].is_cuda and 1 <= A[i].shape[1] <= 8:
+            A[i] = _CandidatesMatvec.apply(A[i], weights[i]).view(B, 1, s, s)
+        else:
+            A[i] = torch.matmul(A[i].transpose(1, 2).float(), weights[i].float()).view(B, 1, s, s)
     return A
 
 
