@@ -105,6 +105,15 @@ int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w_pac
 int rdm_conv2d_wgrad(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale,
                      const float* bn_shift, float* dw_packed, rdm_stream_t stream);
 
+/* rdm_conv2d_fwd with the BatchNorm + ReLU prologue given as the RAW training-mode channel sums (sum x, sum x^2 over bn_count elements,
+ * gamma, beta; eps 1e-5): the kernel forms scale = gamma / sqrt(var + eps), shift = beta - mean * scale itself, with the arithmetic of
+ * rdm_bn_finalize, so the finalisation launch leaves the dependent chain.  Built for the few-pixel blocks only (dense_e4 / decoder d_1 in the
+ * native plan): 1x1 convs on 128 x 48 tiles (<= 32 768 pixels) and 3x3 / pad 1 convs with <= 48 outputs on 128-pixel tiles (<= 8 192 pixels,
+ * width <= 63), in_c <= 768; anything else returns RDM_ERR_BAD_ARGUMENT. */
+int rdm_conv2d_fwd_bnsums(const rdm_conv_desc* d, const float* x, const float* w_packed, const double* bn_sum, const double* bn_sumsq, double bn_count,
+                          const float* bn_gamma, const float* bn_beta, float* y, double* stat_sum, double* stat_sq, int32_t split_k,
+                          rdm_stream_t stream);
+
 /* The same three operators with the K-split chosen by the caller: split_k = 0 keeps the launcher's own choice (what the plain entry
  * points do), 1 forbids splitting (no atomics: one workgroup owns every output element, bit-reproducible), n > 1 asks for n partial
  * sums added with f32 atomics into a zeroed output (the launcher clamps n to the number of K slabs; statistics / bias epilogues

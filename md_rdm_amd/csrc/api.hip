@@ -139,6 +139,25 @@ int rdm_conv2d_fwd_ex(const rdm_conv_desc* d, const float* x, const float* w, co
   return rc < 0 ? rc : RDM_OK;
 }
 
+int rdm_conv2d_fwd_bnsums(const rdm_conv_desc* d, const float* x, const float* w, const double* bn_sum, const double* bn_sumsq, double bn_count,
+                          const float* bn_gamma, const float* bn_beta, float* y, double* stat_sum, double* stat_sq, int32_t split_k, rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_fwd_bnsums: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(x && w && y && bn_sum && bn_sumsq && bn_gamma && bn_beta && bn_count >= 1, "conv2d_fwd_bnsums: NULL operand");
+  RDM_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d_fwd_bnsums: stat_sum and stat_sq go together");
+  FwdArgs a{};
+  a.g = g; a.A = x; a.lda = d->in_ld; a.C = d->in_c;
+  a.a_sum = bn_sum; a.a_sq = bn_sumsq; a.a_gamma = bn_gamma; a.a_beta = bn_beta; a.a_count = bn_count;
+  a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.out = y; a.ldc = d->out_ld; a.M = g.B * g.Ho * g.Wo; a.N = d->out_c;
+  a.stat0 = stat_sum; a.stat1 = stat_sq;
+  a.split_k = split_k;
+  rc = launch_conv_fwd(a, false, stat_sum ? EPI_STORE_STATS : EPI_STORE, stream);
+  return rc < 0 ? rc : RDM_OK;
+}
+
 int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
                      const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, rdm_stream_t stream) {
   return rdm_conv2d_dgrad_ex(d, dy, w, dx, dx_ld, mask_x, mask_ld, mask_scale, mask_shift, stat_a, stat_b, 0, stream);

@@ -7,6 +7,12 @@ int launch_colstats(const float* V, int ldv, int M, int C, double* sum, double* 
 int launch_mask_stats(float* V, int ldv, const float* X, int ldx, const float* xs, const float* xt, int M, int C, double* s0, double* s1, hipStream_t s);
 int launch_bn_finalize(const double* sum, const double* sq, double count, const float* gamma, const float* beta, float* rm, float* rv,
                        long long* nbt, float* scale, float* shift, float* save_mean, float* save_rstd, int C, int training, hipStream_t s);
+// batched training-mode finalisation (k_bn_finalize_batch): entry = channels [0, C) of one BatchNorm; out = [scale | shift | mean | rstd] with
+// row stride Cout (the BatchNorm's full width when only a channel range is finalised)
+struct BnBatchEntry { const double* sum; const double* sq; const float* gamma; const float* beta; float* rm; float* rv; long long* nbt; float* out; double count; int C; int Cout; };
+constexpr int BN_BATCH = 24;
+struct BnBatch { BnBatchEntry e[BN_BATCH]; };
+int launch_bn_finalize_batch(const BnBatch& bb, int count, int max_c, hipStream_t s);
 int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const float* gamma, const float* mean, const float* rstd, float* A,
                          float* Bc, float* Cc, float* dgamma, float* dbeta, int C, int training, hipStream_t s);
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,

@@ -101,23 +101,21 @@ __global__ void k_bn_finalize(const double* sum, const double* sq, double count,
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && num_batches) *num_batches += 1;
   if (c >= C) return;
-  float mean, rstd;
+  float mean, rstd, sc, sh;
   if (training) {
-    const double mu = sum[c] / count;
-    double var = sq[c] / count - mu * mu;
-    if (var < 0) var = 0;
-    mean = (float)mu;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    double var;
+    bn_affine_from_sums(sum[c], sq[c], count, gamma[c], beta[c], eps, sc, sh, mean, rstd, var);
     const double unbiased = count > 1 ? var * count / (count - 1) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   } else {
     mean = running_mean[c];
     rstd = 1.f / sqrtf(running_var[c] + eps);
+    sc = gamma[c] * rstd;
+    sh = beta[c] - mean * sc;
   }
-  const float sc = gamma[c] * rstd;
   scale[c] = sc;
-  shift[c] = beta[c] - mean * sc;
+  shift[c] = sh;
   save_mean[c] = mean;
   save_rstd[c] = rstd;
 }
@@ -127,6 +125,29 @@ int launch_bn_finalize(const double* sum, const double* sq, double count, const 
                        int training, hipStream_t s) {
   hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, sum, sq, count, gamma, beta, rm, rv, nbt, scale, shift,
                      save_mean, save_rstd, C, training, 0.1f, 1e-5f);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// The same finalisation for up to BN_BATCH BatchNorms in ONE launch (blockIdx.y = entry): the bookkeeping of the few-pixel blocks, whose
+// consumers form the affine themselves (RAW prologue), so nothing waits for these values before backward.
+__global__ void k_bn_finalize_batch(BnBatch bb, int training, float momentum, float eps) {
+  const BnBatchEntry& e = bb.e[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && e.nbt) *e.nbt += 1;
+  if (c >= e.C) return;
+  float mean, rstd, sc, sh;
+  double var;
+  bn_affine_from_sums(e.sum[c], e.sq[c], e.count, e.gamma[c], e.beta[c], eps, sc, sh, mean, rstd, var);
+  const double unbiased = e.count > 1 ? var * e.count / (e.count - 1) : var;
+  e.rm[c] = (1.f - momentum) * e.rm[c] + momentum * mean;
+  e.rv[c] = (1.f - momentum) * e.rv[c] + momentum * (float)unbiased;
+  e.out[c] = sc; e.out[e.Cout + c] = sh; e.out[2 * e.Cout + c] = mean; e.out[3 * e.Cout + c] = rstd;
+}
+
+int launch_bn_finalize_batch(const BnBatch& bb, int count, int max_c, hipStream_t s) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(k_bn_finalize_batch, dim3(cdiv(max_c, 256), count), dim3(256), 0, s, bb, 1, 0.1f, 1e-5f);
   RDM_LAUNCH_OK();
   return 0;
 }

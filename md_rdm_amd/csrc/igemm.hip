@@ -170,9 +170,10 @@ __device__ __forceinline__ void conv_epilogue(const FwdArgs& p, f32x4 (&acc)[MT]
 // forward / dgrad kernel: A is an NHWC tensor gathered per filter tap (K-contiguous),
 // B is the packed weight [tap][n][c] read either along c (forward) or along n (dgrad).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI>
+template <int MT, int NT, int WM, int WN, bool TAPS, bool B_KSTRIDED, int EPI, bool RAWBN = false>
 __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
   constexpr int BM = MT * 16 * WM, BN = NT * 16 * WN;
+  __shared__ __attribute__((aligned(16))) float Sbn[RAWBN ? 2 * RAWBN_MAX_C : 4];      // RAWBN: (scale | shift) of the C contracted channels, formed here
   constexpr int LDA = BM + 4, LDB = BN + 4;                        // [k][row] images
   constexpr int AL = (BM * 4 + 255) / 256;                         // float4 loads of A per thread per slab
   constexpr int BL = B_KSTRIDED ? (BK * (BN / 4) + 255) / 256 : (BN * 4 + 255) / 256;
@@ -231,7 +232,15 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       b_voff[i] = (idx < BK * (BN / 4) && n0 + r4 * 4 < p.N) ? (unsigned)k * (unsigned)(p.ldw * 4) + (unsigned)((n0 + r4 * 4) * 4) : OOB;
     }
   }
-  const bool bnrelu = p.a_scale != nullptr;
+  const bool bnrelu = RAWBN || p.a_scale != nullptr;
+  if (RAWBN) {
+    for (int c = tid; c < p.C; c += 256) {
+      float sc, sh, mean, rstd; double var;
+      bn_affine_from_sums(p.a_sum[c], p.a_sq[c], p.a_count, p.a_gamma[c], p.a_beta[c], 1e-5f, sc, sh, mean, rstd, var);
+      Sbn[c] = sc; Sbn[RAWBN_MAX_C + c] = sh;
+    }
+    __syncthreads();
+  }
 
   // slab cursor: channel slab `cs` outer, filter tap (r,q) inner - advanced incrementally (scalar)
   int cur_cs = s_begin, cur_tap = 0, cur_r = 0, cur_q = 0;
@@ -266,7 +275,8 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(FwdArgs p) {
       rok[i] = ok;
       ra[i] = bld4(srdA, ok ? a_voff[i] + a_uni : OOB);
     }
-    if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
+    if (RAWBN) { rsc = ld4(Sbn + c0 + kq_a * 4); rsh = ld4(Sbn + RAWBN_MAX_C + c0 + kq_a * 4); }
+    else if (bnrelu) { rsc = ld4(p.a_scale + c0 + kq_a * 4); rsh = ld4(p.a_shift + c0 + kq_a * 4); }
 #pragma unroll
     for (int i = 0; i < BL; ++i) rb[i] = bld4(srdW, b_voff[i] == OOB ? OOB : b_voff[i] + b_uni);
   };
@@ -432,8 +442,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma256_kernel(FwdArgs p) {
 // fewer global loads, BN-ReLU VALU ops and LDS stores per MFMA.  Weights are staged per tap
 // (double-buffered, one barrier per tap).  Needs 2*(W+1) <= 256 (else the launcher uses the generic path).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int HL, bool DGRAD, int MT>   // HL = float4 halo loads per thread per channel slab = ceil(halo / 64); MT = 16-row tiles per wave
+template <int EPI, int HL, bool DGRAD, int MT, bool RAWBN = false>   // HL = float4 halo loads per thread per channel slab = ceil(halo / 64); MT = 16-row tiles per wave
 __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float Sbn[RAWBN ? 2 * RAWBN_MAX_C : 4];
   // DGRAD: the same machinery run on the output gradient: dx[m][c] = sum_{tap,n} dy[m + (1-r)*W + (1-q)][n] * w[tap][n][c]
   // (taps mirrored, weights read along their input-channel rows), epilogue = ReLU gate + BN-backward sums.
   constexpr int NT = 3, BM = MT * 64, BN = 48;     // MT = 4: 256 pixels per block; MT = 2: 128 (layers with few pixels)
@@ -493,13 +504,22 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
     h_ok[i] = hidx < halo && pix >= 0 && pix < (long)G.B * H * W;
     h_voff[i] = (unsigned)pix * (unsigned)(p.lda * 4) + (unsigned)(kq_a * 16);
   }
-  const bool bnrelu = p.a_scale != nullptr;
+  const bool bnrelu = RAWBN || p.a_scale != nullptr;
+  if (RAWBN) {
+    for (int c = tid; c < p.C; c += 256) {
+      float sc, sh, mean, rstd; double var;
+      bn_affine_from_sums(p.a_sum[c], p.a_sq[c], p.a_count, p.a_gamma[c], p.a_beta[c], 1e-5f, sc, sh, mean, rstd, var);
+      Sbn[c] = sc; Sbn[RAWBN_MAX_C + c] = sh;
+    }
+    __syncthreads();
+  }
   float4 rh[HL], rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_halo = [&](int cs) {
     const unsigned uni = (unsigned)(cs * BK * 4);
 #pragma unroll
     for (int i = 0; i < HL; ++i) rh[i] = bld4(srdA, h_ok[i] ? h_voff[i] + uni : OOB);
-    if (bnrelu) { rsc = ld4(p.a_scale + cs * BK + kq_a * 4); rsh = ld4(p.a_shift + cs * BK + kq_a * 4); }
+    if (RAWBN) { rsc = ld4(Sbn + cs * BK + kq_a * 4); rsh = ld4(Sbn + RAWBN_MAX_C + cs * BK + kq_a * 4); }
+    else if (bnrelu) { rsc = ld4(p.a_scale + cs * BK + kq_a * 4); rsh = ld4(p.a_shift + cs * BK + kq_a * 4); }
   };
   auto store_halo = [&]() {
 #pragma unroll
@@ -1180,6 +1200,14 @@ static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue e
     dim3 grid(cdiv(a.N, 48), cdiv(a.M, bm), sp);
     const int hl = cdiv(bm + 2 * (a.g.W + 1), 64);           // 256-pixel tiles: 5 (W <= 31) .. 8 (<= 127); 128-pixel tiles: 3, 4
     RDM_CENSUS("conv3x3_halo_kernel/%s/px%d/hl%d/%s", halo_dgrad ? "dgrad" : "fwd", bm, small ? std::max(hl, 3) : std::max(hl, 5), epi_name(epi));
+    if (a.a_sum != nullptr) {                     // RAW BatchNorm prologue: the 128-pixel forward tiles of the few-pixel blocks only
+      RDM_CHECK_ARG(small && halo_fwd && a.C <= RAWBN_MAX_C && (epi == EPI_STORE || epi == EPI_ATOMIC), "conv3x3: the raw BatchNorm prologue is built for the 128-pixel forward tiles, C <= %d", RAWBN_MAX_C);
+      RDM_CENSUS("conv3x3_halo_kernel/fwd/px128/hl%d/%s/rawbn", std::max(hl, 3), epi_name(epi));
+      if (epi == EPI_STORE) { if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_STORE, 3, false, 2, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_STORE, 4, false, 2, true>), grid, dim3(256), 0, s, a); }
+      else { if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_ATOMIC, 3, false, 2, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_ATOMIC, 4, false, 2, true>), grid, dim3(256), 0, s, a); }
+      RDM_LAUNCH_OK();
+      return 0;
+    }
 #define RDM_HALO2(E_, D_)                                                                                       \
     if (small) {                                                                                                 \
       if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<E_, 3, D_, 2>), grid, dim3(256), 0, s, a);           \
@@ -1212,6 +1240,17 @@ static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue e
     RDM_CENSUS("conv1x1_dma256_kernel/%s/bn%d", epi_name(epi), bn ? 1 : 0);
     if (epi == EPI_STORE) { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, false>), grid, dim3(256), 0, s, a); }
     else { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, false>), grid, dim3(256), 0, s, a); }
+    RDM_LAUNCH_OK();
+    return 0;
+  }
+  if (a.a_sum != nullptr) {                       // RAW BatchNorm prologue: the 128 x 48 1x1 forward of the few-pixel blocks (conv1 "part B")
+    RDM_CHECK_ARG(!taps && !b_kstrided && cfg == 3 && a.C <= RAWBN_MAX_C && (epi == EPI_STORE_STATS || epi == EPI_STORE || epi == EPI_ATOMIC),
+                  "conv: the raw BatchNorm prologue is built for the 128 x 48 1x1 forward, C <= %d", RAWBN_MAX_C);
+    RDM_CENSUS("conv_fwd_kernel/fwd/1x1/tile128x48/%s/rawbn", epi_name(epi));
+    dim3 grid(cdiv(a.N, 48), cdiv(a.M, 128), split);
+    if (epi == EPI_STORE_STATS) hipLaunchKernelGGL((conv_fwd_kernel<2, 3, 4, 1, false, false, EPI_STORE_STATS, true>), grid, dim3(256), 0, s, a);
+    else if (epi == EPI_STORE) hipLaunchKernelGGL((conv_fwd_kernel<2, 3, 4, 1, false, false, EPI_STORE, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<2, 3, 4, 1, false, false, EPI_ATOMIC, true>), grid, dim3(256), 0, s, a);
     RDM_LAUNCH_OK();
     return 0;
   }

@@ -362,7 +362,8 @@ int finalize_norm1(NetImpl& n, int b, int i, int c_lo, int c_hi, bool count_batc
 }
 
 // conv1 (1x1) of layer i over the input channels [c_lo, c_hi); accumulate => atomically added into a zeroed Y
-int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, bool fuse, void* ws, void* const* T, hipStream_t s, bool add_out = false) {
+int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, bool fuse, void* ws, void* const* T, hipStream_t s, bool add_out = false,
+                bool raw_bn = false) {
   const BlockGeom& g = n.bg[b];
   const LayerIdx& L = reg().layers[b][i];
   const LayerWs& W = n.lws[b][i];
@@ -377,6 +378,11 @@ int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, b
   a.stat0 = sty; a.stat1 = sty + g.cb;
   a.accumulate = accumulate ? 1 : 0;
   a.add_out = add_out ? 1 : 0;
+  if (raw_bn) {          // the consumer forms the BatchNorm affine of its channels from the block's channel sums (no finalisation launch on the chain)
+    double* bst = at<double>(ws, n.blkstat[b]);
+    a.a_scale = nullptr; a.a_shift = nullptr;
+    a.a_sum = bst + c_lo; a.a_sq = bst + g.ctot + c_lo; a.a_gamma = F(T, L.bn1.w) + c_lo; a.a_beta = F(T, L.bn1.b) + c_lo; a.a_count = (double)g.M;
+  }
   const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
   return rc < 0 ? rc : 0;
 }
@@ -394,6 +400,28 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
   const bool pipelined = !fuse_stats(g.M, g.cb) && layers > 1 && g_variant != 8 && !n.opt_det;   // part A / part B add atomically: not in deterministic mode
   hipStream_t side = n.side;
   int rc;
+  // Few-pixel blocks in training (round 3): the two BatchNorm finalisations of a layer leave the dependent chain - the consuming conv
+  // forms (scale, shift) from the channel sums itself (RAW prologue), the running statistics and the coefficients backward needs are written
+  // by BATCHED finalisation launches (24 BatchNorms each) - and the 48-channel output slices of ALL layers are zeroed by ONE launch at the start
+  // of the block (their K-split 3x3 convs then only add).  Per layer: 6 -> 3 launches on the chain, ~2.9 launches fewer in all.
+  const bool raw = pipelined && training && !n.opt_det && g.cb <= RAWBN_MAX_C && !(n.wino_fwd[b] && !n.opt_no_wino) && g.M <= 8192 && 2 * (g.W + 1) <= 128;
+  if (raw && (rc = launch_zero_rows(blk + kBlocks[b].cin, g.M, g.ctot - kBlocks[b].cin, g.ctot, s))) return rc;
+  // RAW mode bookkeeping (running statistics + the coefficients backward reads): nothing in forward waits for it, so it is BATCHED - up to
+  // BN_BATCH BatchNorms per launch, enqueued on the caller's stream once their sums are final (the sums stay untouched until the next forward)
+  BnBatch batch;
+  int nbatch = 0, batch_maxc = 0;
+  auto flush_batch = [&]() -> int {
+    const int r = launch_bn_finalize_batch(batch, nbatch, batch_maxc, s);
+    nbatch = 0; batch_maxc = 0;
+    return r;
+  };
+  auto add_batch = [&](const double* sum, const double* sq, const BnIdx& bn, int c_lo, int c_hi, float* out, int cfull, bool count_batch) -> int {
+    BnBatchEntry& e = batch.e[nbatch++];
+    e.sum = sum + c_lo; e.sq = sq + c_lo; e.gamma = F(T, bn.w) + c_lo; e.beta = F(T, bn.b) + c_lo; e.rm = F(T, bn.rm) + c_lo; e.rv = F(T, bn.rv) + c_lo;
+    e.nbt = count_batch ? static_cast<long long*>(T[bn.nbt]) : nullptr; e.out = out + c_lo; e.count = (double)g.M; e.C = c_hi - c_lo; e.Cout = cfull;
+    batch_maxc = std::max(batch_maxc, c_hi - c_lo);
+    return nbatch == BN_BATCH ? flush_batch() : 0;
+  };
   if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[1], s));        // statistics of the block's input channels are final ("layer -1")
   for (int i = 0; i < layers; ++i) {
     const LayerIdx& L = reg().layers[b][i];
@@ -403,6 +431,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     float* bn2 = at<float>(ws, W.bn2);
     double* sty = at<double>(ws, W.statY);
     // ---- side stream: part A of layer i+1 (channels [0, cin), final once layer i-1 has published its statistics) ----
+    if (raw && i > 0 && (rc = add_batch(bst, bst + g.ctot, L.bn1, cin - GROWTH, cin, at<float>(ws, W.bn1), cin, false))) return rc;   // layer i's newest 48 channels (sums final since layer i-1)
     if (pipelined && i + 1 < layers) {
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_fs[(i + 1) & 1], 0));                 // recorded at the end of layer i-1
       if ((rc = launch_zero_rows(at<float>(ws, n.lws[b][i + 1].Y), 1, (long)g.M * g.cb, (long)g.M * g.cb, side))) return rc;
@@ -414,12 +443,12 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     const bool fuse = training && fuse_stats(g.M, g.cb);
     bool stats_done = false;
     if (pipelined && i > 0) {
-      if ((rc = finalize_norm1(n, b, i, cin - GROWTH, cin, false, ws, T, training, s))) return rc;
+      if (!raw && (rc = finalize_norm1(n, b, i, cin - GROWTH, cin, false, ws, T, training, s))) return rc;
       RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_fa[i & 1], 0));
       if (training && g_variant != 36) {
         // part B is three K-slabs and runs unsplit: its epilogue adds part A's finished sum, stores the final value and takes
         // the channel statistics of it - no separate reduction pass over Y on the critical path (it took 56 us beside part A)
-        if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, false, true, ws, T, s, true))) return rc;
+        if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, false, true, ws, T, s, true, raw))) return rc;
         stats_done = true;
       } else if ((rc = conv1_range(n, b, i, cin - GROWTH, cin, true, false, ws, T, s))) return rc;
     } else {
@@ -427,8 +456,12 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
       if ((rc = conv1_range(n, b, i, 0, cin, false, fuse, ws, T, s))) return rc;
     }
     if (training && !fuse && !stats_done && (rc = launch_colstats(Y, g.cb, g.M, g.cb, sty, sty + g.cb, s))) return rc;
-    if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
-                                 static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
+    if (raw) {                                                          // norm2: the 3x3 conv forms the affine itself; bookkeeping batched (below)
+      if (i > 0 && (rc = add_batch(at<double>(ws, n.lws[b][i - 1].statY), at<double>(ws, n.lws[b][i - 1].statY) + g.cb, reg().layers[b][i - 1].bn2, 0, g.cb,
+                                   at<float>(ws, n.lws[b][i - 1].bn2), g.cb, true)))
+        return rc;                                                      // layer i-1's sums became final one layer ago: no wait for the flush
+    } else if ((rc = launch_bn_finalize(sty, sty + g.cb, (double)g.M, F(T, L.bn2.w), F(T, L.bn2.b), F(T, L.bn2.rm), F(T, L.bn2.rv),
+                                        static_cast<long long*>(T[L.bn2.nbt]), bn2, bn2 + g.cb, bn2 + 2 * g.cb, bn2 + 3 * g.cb, g.cb, training, s)))
       return rc;
     const float* w2p = n.opt_packed3x3 ? F(T, L.conv2) : at<float>(ws, W.w2p);     // else packed on the side stream at the start of forward
     if (b == 0 && i == 0) RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_side, 0));
@@ -438,6 +471,11 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     c.Wt = w2p; c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
     c.out = blk + cin; c.ldc = g.ctot; c.M = g.M; c.N = GROWTH;
     c.stat0 = bst + cin; c.stat1 = bst + g.ctot + cin;
+    if (raw) {
+      c.a_scale = nullptr; c.a_shift = nullptr;
+      c.a_sum = sty; c.a_sq = sty + g.cb; c.a_gamma = F(T, L.bn2.w); c.a_beta = F(T, L.bn2.b); c.a_count = (double)g.M;
+      c.accumulate = 1;                                                 // the slice was zeroed with the whole block at its start
+    }
     if (n.wino_fwd[b] && !n.opt_no_wino) {
       // Winograd F(2x2, 3x3): the ordered reduction of the split partials also takes the channel statistics (no zero fill, no separate pass)
       WinoConv wv{};
@@ -452,6 +490,12 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
       if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
     }
     if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[i & 1], s));     // layer i's output channels + their statistics are final
+  }
+  if (raw) {                                                            // the last layer's norm2, then whatever is left in the batch
+    const int i = layers - 1;
+    if ((rc = add_batch(at<double>(ws, n.lws[b][i].statY), at<double>(ws, n.lws[b][i].statY) + g.cb, reg().layers[b][i].bn2, 0, g.cb, at<float>(ws, n.lws[b][i].bn2), g.cb, true)))
+      return rc;
+    if ((rc = flush_batch())) return rc;
   }
   return 0;
 }

@@ -97,7 +97,25 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   int add_out;                                // EPI_STORE_STATS: out = out + v (the statistics are taken of the SUM): completes a K-partial
   int accumulate;                             // 1: add into `out` (f32 atomics), never zero it - the caller owns the initial value
   unsigned a_bytes, w_bytes;                  // set by the launcher: addressable extents of A / Wt (buffer descriptors)
+  // RAW BatchNorm prologue (training, few-pixel blocks): instead of finished (a_scale, a_shift) the kernel gets the channel sums and forms
+  // the affine itself - the k_bn_finalize launch (5-9 us + a dependent-launch gap) leaves the critical chain; C <= RAWBN_MAX_C
+  const double* a_sum; const double* a_sq; const float* a_gamma; const float* a_beta; double a_count;
 };
+constexpr int RAWBN_MAX_C = 768;
+
+// scale / shift of a training-mode BatchNorm from the channel sums: THE arithmetic of k_bn_finalize (elementwise.hip), shared so that the
+// in-kernel prologue and the finalisation kernel agree bit for bit
+__device__ __forceinline__ void bn_affine_from_sums(double sum, double sq, double count, float gamma, float beta, float eps, float& scale, float& shift,
+                                                    float& mean, float& rstd, double& var_out) {
+  const double mu = sum / count;
+  double var = sq / count - mu * mu;
+  if (var < 0) var = 0;
+  mean = (float)mu;
+  rstd = (float)(1.0 / sqrt(var + (double)eps));
+  scale = gamma * rstd;
+  shift = beta - mean * scale;
+  var_out = var;
+}
 
 struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)][c])
   ConvGeom g;

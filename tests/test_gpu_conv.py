@@ -375,6 +375,55 @@ def test_conv1x1_big_grid_dgrad_and_small_grid_split(cin):
     _RAN.add(("dgrad_big", cin))
 
 
+@pytest.mark.parametrize("case", [(16, 15, 19, 48, 2112, 720, 1, 1), (16, 15, 19, 720, 720, 48, 3, 3), (16, 8, 10, 384, 384, 48, 3, 3), (16, 8, 10, 48, 2208, 384, 1, 1)],
+                         ids=["e4_1x1", "e4_3x3", "d1_3x3", "d1_1x1"])
+def test_conv_fwd_with_raw_batchnorm_sums(case):
+    """rdm_conv2d_fwd_bnsums: the BatchNorm + ReLU prologue formed INSIDE the conv from the channel sums (what the plan's few-pixel blocks
+    run in training, so that no k_bn_finalize launch sits on the dependent chain) vs float64, and bit-identical with rdm_bn_finalize ->
+    rdm_conv2d_fwd on the same sums (same arithmetic)."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cin, ld, Cout, kh, kw = case
+    M = B * H * W
+    g = torch.Generator().manual_seed(77 + Cin + kh)
+    x = torch.randn(B, H, W, ld, generator=g) * 1.5 + 0.4
+    w = torch.randn(kh * kw, Cout, Cin, generator=g) / (Cin * kh * kw) ** 0.5
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xs = x[..., :Cin].double().reshape(M, Cin)
+    mean, var = xs.mean(0), xs.var(0, unbiased=False)
+    a = torch.relu((xs - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()).reshape(B, H, W, Cin)
+    want = _ref3x3(a, w.double()) if kh == 3 else a.reshape(M, Cin) @ w[0].double().t()
+    xg, wg, gg, bg = x.to(dev), w.to(dev), gamma.to(dev), beta.to(dev)
+    ssum = torch.zeros(Cin, dtype=torch.float64, device=dev)
+    ssq = torch.zeros_like(ssum)
+    check(L.rdm_bn_stats(ptr(xg), ld, M, Cin, ptr(ssum), ptr(ssq), stream()))
+    d = ConvDesc(B, H, W, Cin, ld, Cout, Cout, kh, kw, 1, 1, kh // 2, kw // 2)
+    pad = kh // 2
+    outs = []
+    for split, stats in ((1, kh == 1), (1, False), (3, False)):       # the statistics epilogue exists for the 1x1 (conv1 "part B") only
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        s0 = torch.zeros(Cout, dtype=torch.float64, device=dev)
+        s1 = torch.zeros_like(s0)
+        check(L.rdm_conv2d_fwd_bnsums(C.byref(d), ptr(xg), ptr(wg), ptr(ssum), ptr(ssq), float(M), ptr(gg), ptr(bg), ptr(y), ptr(s0) if stats else None,
+                                      ptr(s1) if stats else None, split, stream()))
+        assert rel(y.cpu().double(), want) < TOL, (split, stats)
+        if stats:
+            assert rel(s0.cpu(), want.sum(0)) < 1e-5 and rel(s1.cpu(), (want ** 2).sum(0)) < 1e-5
+        outs.append(y)
+    # the same result, bit for bit, through the finalisation kernel (unsplit)
+    coef = torch.empty(4, Cin, device=dev)
+    rm, rv, nbt = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    check(L.rdm_bn_finalize(ptr(ssum), ptr(ssq), float(M), ptr(gg), ptr(bg), ptr(rm), ptr(rv), ptr(nbt), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), Cin, 1, stream()))
+    y2 = torch.empty(M, Cout, device=dev)
+    check(L.rdm_conv2d_fwd_ex(C.byref(d), ptr(xg), ptr(wg), None, ptr(coef[0]), ptr(coef[1]), ptr(y2), None, None, 1, stream()))
+    assert torch.equal(outs[1], y2)
+    cen = _lib.census()
+    assert any(k.endswith("/rawbn") for k in cen), sorted(cen)
+    _RAN.add(("rawbn",) + case)
+
+
 def test_conv_linearity_full_size():
     """Size-independent property at the bench geometry (B=16, 57x76, 96->2736): conv(a*x1+b*x2) == a*conv(x1)+b*conv(x2)."""
     from md_rdm_amd import _lib
