@@ -166,6 +166,20 @@ int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, con
 size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w);
 int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* scale, const float* shift, const void* w_packed, void* out,
                      int32_t ldc, int32_t batch, int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+/* The same 3x3 on an ALREADY ACTIVATED input (the form rdm_net_forward_bf16 runs: in eval mode the producing 1x1 applies BatchNorm +
+ * ReLU in its epilogue - rdm_gemm_bf16_act - so the 3x3 has no prologue and both operands reach LDS by DMA, zero padding included):
+ *   rdm_conv3x3_act_bf16_pack  w (48, channels, 3, 3) f32 OIHW -> the fragment-order bf16 image the kernel streams
+ *                              (rdm_conv3x3_act_bf16_weight_bytes(channels) bytes; channels are padded to a multiple of 32 with zeros).
+ *   rdm_conv3x3_act_bf16       y (B,H,W, ldy) bf16, `channels_padded` = the multiple of 32 the image was packed for (<= ldy; activations
+ *                              behind the real channel count must be finite: their weights are zero), out (B*H*W, ldc) bf16.
+ *                              workspace (optional, 256-byte aligned, rdm_conv3x3_act_bf16_workspace_bytes): tile counters + f32 partial
+ *                              sums of a K-split; the last workgroup of a tile adds them in a fixed order inside the same launch (deterministic).
+ *                              RDM_ERR_UNSUPPORTED (nothing launched) when a tile's rows do not fit the 160 KB LDS (rows wider than ~250 pixels). */
+size_t rdm_conv3x3_act_bf16_weight_bytes(int32_t channels);
+int rdm_conv3x3_act_bf16_pack(const float* w_oihw, int32_t channels, void* w_image, rdm_stream_t stream);
+size_t rdm_conv3x3_act_bf16_workspace_bytes(int32_t channels_padded, int32_t batch, int32_t h, int32_t w);
+int rdm_conv3x3_act_bf16(const void* y_act, int32_t ldy, int32_t channels_padded, const void* w_image, void* out, int32_t ldc, int32_t batch,
+                         int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm / pooling pieces of the conv stack as operators (the plan below enqueues the same kernels).

@@ -50,6 +50,10 @@ _SIGNATURES = {
     "rdm_gemm_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "rdm_conv3x3_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "rdm_conv3x3_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "rdm_conv3x3_act_bf16_weight_bytes": (sz, [i32]),
+    "rdm_conv3x3_act_bf16_pack": (C.c_int, [vp, i32, vp, vp]),
+    "rdm_conv3x3_act_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "rdm_conv3x3_act_bf16": (C.c_int, [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "rdm_bn_stats": (C.c_int, [vp, i32, i64, i32, vp, vp, vp]),
     "rdm_bn_finalize": (C.c_int, [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "rdm_bn_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, vp, i64, i32, vp, vp, vp]),

@@ -304,6 +304,36 @@ int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* 
   return launch_conv3x3_bf16(a, stream);
 }
 
+size_t rdm_conv3x3_act_bf16_weight_bytes(int32_t channels) { return channels > 0 ? (size_t)cdiv(channels, 32) * 27 * 1024 : 0; }
+
+int rdm_conv3x3_act_bf16_pack(const float* w_oihw, int32_t channels, void* w_image, rdm_stream_t stream) {
+  RDM_CHECK_ARG(w_oihw && w_image && channels > 0 && ((uintptr_t)w_image & 15) == 0, "conv3x3_act_bf16_pack: bad argument");
+  return launch_pack_w3_frag_bf16(w_oihw, w_image, channels, cdiv(channels, 32) * 32, 0, stream);
+}
+
+static const size_t kActCounterBytes = 16384;                // 4096 tile counters in front of the partial sums
+
+size_t rdm_conv3x3_act_bf16_workspace_bytes(int32_t channels_padded, int32_t batch, int32_t h, int32_t w) {
+  if (channels_padded <= 0 || batch <= 0 || h <= 0 || w <= 0) return 0;
+  return kActCounterBytes + conv3x3_act_partial_floats(channels_padded, batch, h, w) * sizeof(float);
+}
+
+int rdm_conv3x3_act_bf16(const void* y_act, int32_t ldy, int32_t channels_padded, const void* w_image, void* out, int32_t ldc, int32_t batch,
+                         int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(!workspace || ((uintptr_t)workspace & 255) == 0, "conv3x3_act_bf16: workspace must be 256-byte aligned");
+  RDM_CHECK_ARG(y_act && w_image && out && batch > 0 && h > 0 && w > 0 && channels_padded > 0 && ldy >= channels_padded && ldc >= 48, "conv3x3_act_bf16: bad argument");
+  RDM_CHECK_ARG((long)batch * h * w < (1L << 30), "conv3x3_act_bf16: too many pixels for 32-bit indices");
+  Conv3ActArgs a{};
+  a.Y = y_act; a.ldy = ldy; a.C = channels_padded; a.Wimg = w_image; a.out = static_cast<unsigned short*>(out); a.ldc = ldc; a.B = batch; a.H = h; a.W = w;
+  if (workspace && workspace_bytes > kActCounterBytes) {
+    a.counters = static_cast<unsigned*>(workspace); a.n_counters = (int)(kActCounterBytes / 4);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kActCounterBytes);
+    a.partial_floats = (workspace_bytes - kActCounterBytes) / sizeof(float);
+    RDM_HIP_OK(hipMemsetAsync(workspace, 0, kActCounterBytes, stream));        // the counters are self-resetting; a caller's buffer starts in an unknown state
+  }
+  return launch_conv3x3_act_bf16(a, stream);
+}
+
 static int check_nhwc(const void* p, int ld, int channels, const char* what) {
   RDM_CHECK_ARG(p != nullptr, "%s: NULL tensor", what);
   RDM_CHECK_ARG(channels > 0 && channels % 4 == 0 && ld >= channels && ld % 4 == 0, "%s: channels (%d) and pixel stride (%d) must be multiples of 4, stride >= channels", what, channels, ld);

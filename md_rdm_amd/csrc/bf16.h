@@ -25,7 +25,23 @@ struct Conv3Bf16Args {       // out[m][n] = sum_{tap,c} relu(Y[pix(m,tap)][c]*sc
   unsigned y_bytes, w_bytes, p_bytes;
 };
 
+struct Conv3ActArgs {        // out[m][n] = sum_{tap,c} Y[pix(m,tap)][c] * w[n][c][tap] on an ALREADY ACTIVATED input, zero padding, n < 48
+  const void* Y; int ldy; int C;           // bf16 [B*H*W][ldy]; C multiple of 32 (pad channels: finite values, their weights are zero)
+  const void* Wimg;                        // fragment-order weight image (launch_pack_w3_frag_bf16): C/32 slabs of 27 KiB
+  unsigned short* out; int ldc;            // bf16 [B*H*W][ldc]
+  int B, H, W;
+  float* partial; size_t partial_floats;   // optional f32 scratch for the K-split ([tile][split][BM][48])
+  unsigned* counters; int n_counters;      // one per tile, ZERO on entry, left zero (needed when partial != NULL)
+  int split, slots, tiles_per_img;         // set by the launcher
+  unsigned y_bytes, w_bytes;
+  int abl;                                 // development builds: ablation bits (0 in the shipped build)
+};
+
 int launch_gemm_bf16(const GemmBf16Args& a, bool out_f32, hipStream_t s);
+int launch_conv3x3_act_bf16(const Conv3ActArgs& a, hipStream_t s);      // RDM_ERR_UNSUPPORTED when the geometry does not fit the LDS (nothing launched)
+size_t conv3x3_act_partial_floats(int C, int B, int H, int W);          // scratch the heuristic would like
+int conv3x3_act_tiles(int B, int H, int W);                             // upper bound of the tile count (counters needed)
+int launch_pack_w3_frag_bf16(const float* w, void* img, int C, int Cpad, int packed, hipStream_t s);
 int launch_conv3x3_bf16(const Conv3Bf16Args& a, hipStream_t s);
 int launch_f32_to_bf16_rows(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int cols_pad, hipStream_t s);
 int launch_pack_w_bf16(const float* w_oihw, void* w_packed, int O, int I, int T, hipStream_t s);

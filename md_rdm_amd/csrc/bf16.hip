@@ -385,6 +385,220 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 / 48 outputs on an ALREADY ACTIVATED input (the producing 1x1 applied BatchNorm + ReLU in its epilogue:
+// eval mode knows the affine ahead of time), both operands by LDS-DMA.
+//   * no prologue  => no staging registers, no BN-ReLU VALU work, no ds_write: `buffer_load_dwordx4 ... lds` moves 1-KiB pieces
+//     (64 lanes x 16 B) straight into the LDS image; zero padding = out-of-range source offsets (the DMA writes zeros);
+//   * a workgroup of NW wave64s owns BM = NW*64 consecutive pixels of ONE image (tiles never straddle images), every wave a
+//     64 x 48 output tile (48 accumulator registers); per 32-channel slab it needs the zero-padded image rows of the tile
+//     ([slot][32 ch] bf16, 16-byte chunks XOR-swizzled on the SOURCE side as in conv3x3_bf16_kernel) and the slab's weights in
+//     MFMA-FRAGMENT order ([tap][n-tile][lane][8 bf16]: one 1-KiB piece per fragment, read back conflict-free at lane*16);
+//   * 2 stages (image + 27 KiB of weights each), ONE barrier per slab: wait own DMAs -> barrier -> issue slab s+1 -> 108 MFMAs;
+//   * K-split over grid.y: partial sums to f32 slabs; the LAST workgroup of a tile to arrive (agent-scope counter behind
+//     __threadfence) adds them in ascending split order - no second launch, no atomics on data, same bits every run.
+// C must be a multiple of 32 (the network pads its bottleneck widths; pad channels are zero on both operands).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned char* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_act_bf16_kernel(Conv3ActArgs p) {
+  constexpr int MT = 4, NT = 3, BM = NW * 64, HP = 8, WPIECES = 27, WBYTES = WPIECES * 1024, NTHR = NW * 64;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int stage_bytes = p.slots * 64 + WBYTES;                     // image, then the weight fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;   // (uniform: LDS-DMA targets go to M0)
+  const int W = p.W, H = p.H, Wp = W + 2, HW = H * W;
+  const int tile = blockIdx.x, b = tile / p.tiles_per_img, t = tile - b * p.tiles_per_img;
+  const int ml0 = t * BM, mlN = min(HW, ml0 + BM);                    // this tile's pixels inside image b
+  const int y0 = ml0 / W, y1 = (mlN - 1) / W;
+  const int nslots = (y1 - y0 + 3) * Wp, npieces = (nslots + 15) >> 4;   // padded rows y0-1 .. y1+1; <= p.slots / 16 (launcher)
+  const __amdgpu_buffer_rsrc_t srdY = srd(p.Y, p.y_bytes), srdW = srd(p.Wimg, p.w_bytes);
+
+  // image pieces of this wave: piece q = wave + i*NW covers slots 16q .. 16q+15; lane -> (slot, LDS chunk); the SOURCE chunk is swizzled
+  unsigned voff[HP];
+#pragma unroll
+  for (int i = 0; i < HP; ++i) {
+    const int sl = (wave + i * NW) * 16 + (lane >> 2), c = (lane & 3) ^ (((sl >> 2) & 1) << 1);
+    const int prow = sl / Wp, x = sl - prow * Wp - 1, y = y0 - 1 + prow;
+    const bool ok = sl < nslots && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    voff[i] = ok ? (unsigned)((b * H + y) * W + x) * (unsigned)(p.ldy * 2) + (unsigned)(c * 16) : OOB;
+  }
+  const unsigned wvoff = (unsigned)(lane * 16);
+  auto issue = [&](int st, int cs) {
+    unsigned char* const base = smem + st * stage_bytes;
+    const unsigned so = (unsigned)cs * 64u;
+#ifdef RDM_DEV_VARIANTS
+    if (!(p.abl & 1))
+#endif
+#pragma unroll
+    for (int i = 0; i < HP; ++i)
+      if (wave + i * NW < npieces) dma16(srdY, voff[i], so, base + (wave + i * NW) * 1024);
+    unsigned char* const wb = base + p.slots * 64;
+    const unsigned wso = (unsigned)cs * (unsigned)WBYTES;
+#ifdef RDM_DEV_VARIANTS
+    if (!(p.abl & 2))
+#endif
+#pragma unroll
+    for (int q = 0; q < (WPIECES + NW - 1) / NW; ++q)
+      if (wave + q * NW < WPIECES) dma16(srdW, wvoff + (unsigned)((wave + q * NW) * 1024), wso, wb + (wave + q * NW) * 1024);
+  };
+
+  // LDS byte address (inside a stage) of the activation fragment of (m-tile i, tap): slot of the lane's pixel shifted by the tap
+  const bool active = ml0 + wave * 64 < mlN;                          // ragged last tile of an image: idle waves only stage and synchronise
+  unsigned faddr[MT][9];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ml = min(ml0 + wave * 64 + i * 16 + l16, mlN - 1);     // rows past the tile are never stored: any in-range address will do
+    const int y = ml / W, x = ml - y * W;
+    const int sc = (y - y0 + 1) * Wp + x + 1;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int sl = sc + (tp / 3 - 1) * Wp + (tp % 3 - 1);
+      faddr[i][tp] = (unsigned)(sl * 64 + ((g ^ (((sl >> 2) & 1) << 1)) << 4));
+    }
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ncs_all = p.C >> 5, split = (int)gridDim.y;
+  const int per = (ncs_all + split - 1) / split;
+  const int cs0 = blockIdx.y * per, cs1 = min(ncs_all, cs0 + per);   // the launcher leaves no split empty
+  issue(0, cs0);
+  for (int cs = cs0; cs < cs1; ++cs) {
+    const int st = (cs - cs0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of slab cs have landed (nothing younger is in flight)
+    __builtin_amdgcn_s_barrier();                                     // ... and everybody's; every wave is past its reads of the other stage
+    asm volatile("" ::: "memory");
+    if (cs + 1 < cs1) issue(st ^ 1, cs + 1);
+#ifdef RDM_DEV_VARIANTS
+    if (active && !(p.abl & 4)) {
+#else
+    if (active) {
+#endif
+      // fragments of tap t+1 are read while the 12 MFMAs of tap t run (two register sets; the scheduler is pinned, it would otherwise
+      // fold both sets into one and wait for every read)
+      const unsigned char* const ib = smem + st * stage_bytes;
+      const unsigned char* const wb = ib + p.slots * 64 + lane * 16;
+      bf16x8 wf[2][NT], xf[2][MT];
+      auto frags = [&](int set, int tp) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(wb + (tp * 3 + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(ib + faddr[i][tp]);
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        if (tp < 8) frags((tp + 1) & 1, tp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp & 1][j], xf[tp & 1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const long pix0 = (long)b * HW + ml0;
+  if (split == 1) {
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = j * 16 + g * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int r = wave * 64 + i * 16 + l16;
+        if (ml0 + r < mlN)
+          *reinterpret_cast<uint2*>(p.out + (pix0 + r) * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
+      }
+    }
+    return;
+  }
+  // K-split: this workgroup's partial sums, then the last arrival of the tile adds the `split` slabs in ascending order.
+  // Coherence across the 8 XCD L2s WITHOUT cache-wide fences (a __threadfence pair per workgroup writes back and invalidates a whole
+  // L2 each time: measured 65 us of a 170 us launch): the partial sums are written and read with agent-scope (sc1) accesses, which
+  // go through to the memory side; ordering = this wave's stores acknowledged (vmcnt(0)) -> workgroup barrier -> ticket (device-scope
+  // atomic at the memory side) -> the last workgroup's sc1 loads.
+  const __amdgpu_buffer_rsrc_t srdP = srd(p.partial + (size_t)tile * split * (size_t)(BM * 48), (unsigned)(split * BM * 48 * 4));
+  if (active) {
+    const unsigned mine = (unsigned)blockIdx.y * (unsigned)(BM * 48 * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = j * 16 + g * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int r = wave * 64 + i * 16 + l16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), srdP, (int)(mine + (unsigned)(r * 48 + n) * 4u), 0, 16);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  volatile int* const flag = reinterpret_cast<volatile int*>(smem);   // every wave is past its last fragment read
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = ticket == (unsigned)(split - 1);
+    if (ticket == (unsigned)(split - 1)) __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+  }
+  __syncthreads();
+  if (!*flag) return;
+  // every thread owns 12 float4 of the tile (BM*12 / NTHR); a slab element comes from the memory side (~1.5 us): all loads of 6
+  // elements x 6 slabs are issued before the first add - 2 round trips for a split <= 6 instead of 12 x split
+  const int nrow = mlN - ml0;
+  constexpr int G = 6, ZB = 6;
+#pragma unroll
+  for (int k0 = 0; k0 < 12; k0 += G) {
+    f32x4 a[G];
+    unsigned off[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int idx = tid + (k0 + k) * NTHR, r = idx / 12;
+      off[k] = r < nrow ? (unsigned)idx * 16u : OOB;                  // idx*16 = (r*48 + q4*4)*4
+      a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int z0 = 0; z0 < split; z0 += ZB) {
+      f32x4 v[G][ZB];
+#pragma unroll
+      for (int z = 0; z < ZB; ++z)
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+          v[k][z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, (int)((z0 + z < split && off[k] != OOB) ? off[k] + (unsigned)(z0 + z) * (unsigned)(BM * 48 * 4) : OOB), 0, 16));
+#pragma unroll
+      for (int z = 0; z < ZB; ++z)                                    // ascending split order; slabs past `split` read as +0
+#pragma unroll
+        for (int k = 0; k < G; ++k) { a[k][0] += v[k][z][0]; a[k][1] += v[k][z][1]; a[k][2] += v[k][z][2]; a[k][3] += v[k][z][3]; }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int idx = tid + (k0 + k) * NTHR, r = idx / 12, q4 = idx - r * 12;
+      if (r < nrow) *reinterpret_cast<uint2*>(p.out + (pix0 + r) * p.ldc + q4 * 4) = make_uint2(pack2(a[k][0], a[k][1]), pack2(a[k][2], a[k][3]));
+    }
+  }
+}
+
+// 3x3 weights -> the fragment-order image conv3x3_act_bf16_kernel streams: img[slab][tap][n-tile j][lane][e] = w[n = 16j + (lane & 15)]
+// [c = 32 slab + 8 (lane >> 4) + e][tap]; c >= C -> 0.  Source: PyTorch OIHW [48][C][9] (packed = 0) or [9][48][C] (packed = 1).
+__global__ __launch_bounds__(256) void k_pack_w3_frag_bf16(const float* __restrict__ w, unsigned short* __restrict__ img, int C, int Cpad, int packed) {
+  const long total = (long)(Cpad / 32) * 27 * 64 * 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long f = i >> 9;                                                   // (slab*9 + tap)*3 + j
+    const int j = (int)(f % 3); f /= 3;
+    const int tap = (int)(f % 9), slab = (int)(f / 9);
+    const int n = j * 16 + (lane & 15), c = slab * 32 + (lane >> 4) * 8 + e;
+    float v = 0.f;
+    if (c < C) v = packed ? w[((long)tap * 48 + n) * C + c] : w[((long)n * C + c) * 9 + tap];
+    img[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  }
+}
+
 // out[m][n .. n+3] = bf16(sum_s partial[s][m][n .. n+3]) in a fixed order (s ascending): the reduction of the K-split
 __global__ __launch_bounds__(256) void k_reduce_partials_bf16(const float* __restrict__ partial, int split, long MN4, int n4, unsigned short* __restrict__ out, int ldc) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
@@ -648,6 +862,94 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
     const long mn4 = (long)a.M * 12;
     hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, 12, a.out, a.ldc);
   }
+  profile_end(tk, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+
+// ---- conv3x3_act_bf16_kernel: tile / split choice ----
+namespace {
+struct Conv3ActPlan { int nw = 0, split = 1, slots = 0, tpi = 0; size_t lds = 0; double cost = 0; };
+// max zero-padded LDS slots (multiple of 16) over the tiles of one image
+int act_slots(int H, int W, int bm) {
+  const int HW = H * W, tpi = cdiv(HW, bm);
+  int rows = 0;
+  for (int t = 0; t < tpi; ++t) rows = std::max(rows, (std::min(HW, (t + 1) * bm) - 1) / W - (t * bm) / W + 3);
+  return (rows * (W + 2) + 15) & ~15;
+}
+bool plan_conv3_act(int C, int B, int H, int W, size_t partial_floats, int n_counters, Conv3ActPlan& best) {
+  const int HW = H * W, slabs = C / 32;
+  best = Conv3ActPlan{};
+  for (int nw = 2; nw <= 8; ++nw) {
+    const int bm = nw * 64, tpi = cdiv(HW, bm), slots = act_slots(H, W, bm);
+    if (slots > 128 * nw) continue;                                   // 8 pieces per wave
+    const size_t lds = 2 * ((size_t)slots * 64 + 27 * 1024);
+    if (lds > 160 * 1024) continue;
+    const long tiles = (long)B * tpi;
+    const int res = (int)std::max<size_t>(1, std::min<size_t>((size_t)(8 / nw), (160 * 1024) / lds));   // workgroups per CU (2 waves per SIMD, LDS)
+    for (int sp = 1; sp <= std::min(slabs, 32); ++sp) {
+      const int per = cdiv(slabs, sp), spe = cdiv(slabs, per);
+      if (spe != sp) continue;
+      if (spe > 1 && ((size_t)tiles * spe * bm * 48 > partial_floats || tiles > n_counters)) break;
+      const long blocks = tiles * spe, rounds = cdiv(blocks, 256L * res);
+      const int wps = cdiv(nw * (int)std::min<long>(res, cdiv(blocks, 256L)), 4);      // waves sharing a SIMD
+      // microseconds: per slab 0.42 (one wave per SIMD) / 0.75 (two); prologue + epilogue 2.5; ordered combine: 2 memory round trips per 6 slabs
+      const double cost = (double)rounds * (per * (wps > 1 ? 0.75 : 0.42) + 2.5) + (spe > 1 ? 1.0 + 2 * cdiv(spe, 6) * 1.7 : 0.0);
+      if (best.nw == 0 || cost < best.cost * 0.98) { best.nw = nw; best.split = spe; best.slots = slots; best.tpi = tpi; best.lds = lds; best.cost = cost; }
+    }
+  }
+  return best.nw != 0;
+}
+}  // namespace
+
+size_t conv3x3_act_partial_floats(int C, int B, int H, int W) {
+  // enough for a split of 8 on 512-pixel tiles (the heuristic takes what it is given)
+  const long tiles = (long)B * cdiv(H * W, 128);
+  return (size_t)tiles * 128 * 48 * (size_t)std::min(std::max(C / 64, 1), 8) + (size_t)B * 8 * 512 * 48;
+}
+int conv3x3_act_tiles(int B, int H, int W) { return B * cdiv(H * W, 128); }
+
+int launch_pack_w3_frag_bf16(const float* w, void* img, int C, int Cpad, int packed, hipStream_t s) {
+  RDM_CHECK_ARG(C > 0 && Cpad >= C && Cpad % 32 == 0, "pack_w3_frag_bf16: padded channel count (%d) must be a multiple of 32 >= %d", Cpad, C);
+  const long total = (long)(Cpad / 32) * 27 * 512;
+  hipLaunchKernelGGL(k_pack_w3_frag_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, w, static_cast<unsigned short*>(img), C, Cpad, packed);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
+  Conv3ActArgs a = a_in;
+  RDM_CHECK_ARG(a.C > 0 && a.C % 32 == 0 && a.ldy % 8 == 0 && a.ldc % 4 == 0, "conv3x3_act_bf16: C (%d) must be a multiple of 32, the strides of 8 / 4", a.C);
+  RDM_CHECK_ARG((((uintptr_t)a.Y | (uintptr_t)a.Wimg) & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "conv3x3_act_bf16: operands must be 16-byte aligned");
+  const long M = (long)a.B * a.H * a.W;
+  const long yb = ((M - 1) * a.ldy + a.C) * 2, wb = (long)(a.C / 32) * 27 * 1024;
+  if (yb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("conv3x3_act_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
+  a.y_bytes = (unsigned)yb; a.w_bytes = (unsigned)wb;
+  Conv3ActPlan pl;
+  const bool can_split = a.partial && a.counters;
+  if (!plan_conv3_act(a.C, a.B, a.H, a.W, can_split ? a.partial_floats : 0, can_split ? a.n_counters : 0, pl)) {
+    set_error("conv3x3_act_bf16: rows of %d pixels do not fit the LDS image", a.W);
+    return RDM_ERR_UNSUPPORTED;
+  }
+  a.split = pl.split; a.slots = pl.slots; a.tiles_per_img = pl.tpi;
+#ifdef RDM_DEV_VARIANTS
+  a.abl = g_variant >= 100 && g_variant < 116 ? g_variant - 100 : 0;
+#endif
+  void* tk = profile_begin(s, 2.0 * M * 48.0 * a.C * 9.0, 8, 2.0 * ((double)M * a.C + 9.0 * 48 * a.C + (double)M * 48));
+  dim3 grid((unsigned)(a.B * pl.tpi), (unsigned)pl.split);
+#define RDM_C3A(NW_)                                                                                                                      \
+  case NW_: {                                                                                                                              \
+    static bool attr_set = false;                                                                                                          \
+    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_act_bf16_kernel<NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+    hipLaunchKernelGGL((conv3x3_act_bf16_kernel<NW_>), grid, dim3(NW_ * 64), pl.lds, s, a);                                                \
+  } break
+  switch (pl.nw) {
+    RDM_C3A(2); RDM_C3A(3); RDM_C3A(4); RDM_C3A(5); RDM_C3A(6); RDM_C3A(7); RDM_C3A(8);
+    default: set_error("conv3x3_act_bf16: bad plan"); return RDM_ERR_UNSUPPORTED;
+  }
+#undef RDM_C3A
+  RDM_CENSUS("conv3x3_act_bf16_kernel/nw%d/%s", pl.nw, pl.split > 1 ? "splitK" : "direct");
   profile_end(tk, s);
   RDM_LAUNCH_OK();
   return 0;

@@ -163,3 +163,43 @@ def test_conv3x3_bf16_operator(dev, B, H, W, Cc):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _lib.check(L.rdm_conv3x3_bf16(P(Y), Cc, Cc, P(sc), P(sh), P(wp), C.c_void_p(out2.data_ptr() + 2 * 16), ldc, B, H, W, P(ws), wsb, st))
         assert torch.equal(out2[:, 16:64].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 57, 76, 2736), (8, 29, 38, 1392), (3, 15, 19, 720), (2, 8, 10, 384), (1, 11, 38, 384), (1, 23, 90, 96),
+                                      (5, 9, 13, 64)])
+def test_conv3x3_act_bf16_operator(dev, op_census, B, H, W, Cc):
+    """rdm_conv3x3_act_bf16 (input already activated, both operands by LDS-DMA, zero padding by out-of-range source offsets, K-split
+    combined inside the launch by the tile's last workgroup) vs torch conv2d in f32 on the same bf16-rounded operands.  Channel counts
+    48*odd are padded to a multiple of 32 (finite garbage behind the real channels: their weights are zero); the shapes take tiles of
+    2..8 waves, ragged last tiles of an image, rows that wrap inside a 16-pixel fragment, with and without the split."""
+    from md_rdm_amd import _lib
+    L, st, P = _lib.lib(), _lib.stream(), _lib.ptr
+    M = B * H * W
+    Cp = (Cc + 31) // 32 * 32
+    ldy = Cp + 8
+    Yf = torch.full((B, H, W, ldy), 3.0, device=dev)
+    Yf[..., :Cc] = torch.relu(torch.from_numpy(U(f"c3a.y{H}", (B, H, W, Cc), -2.0, 2.0)).to(dev))
+    Y = Yf.bfloat16()
+    w = torch.from_numpy(U(f"c3a.w{Cc}", (48, Cc, 3, 3), -0.05, 0.05)).to(dev)
+    wimg = torch.empty(int(L.rdm_conv3x3_act_bf16_weight_bytes(Cc)), dtype=torch.uint8, device=dev)
+    _lib.check(L.rdm_conv3x3_act_bf16_pack(P(w), Cc, P(wimg), st))
+    want = F.conv2d(Y[..., :Cc].float().permute(0, 3, 1, 2), w.bfloat16().float(), padding=1).permute(0, 2, 3, 1).reshape(M, 48)
+    ldc = 96
+    wsb = int(L.rdm_conv3x3_act_bf16_workspace_bytes(Cp, B, H, W))
+    outs = []
+    for ws_bytes in (0, wsb, 16384 + 2 * 512 * 48 * 4 * B * ((H * W + 127) // 128)):     # unsplit, the heuristic's split, a tight scratch
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+        out = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.rdm_conv3x3_act_bf16(P(Y), ldy, Cp, P(wimg), C.c_void_p(out.data_ptr() + 2 * 16), ldc, B, H, W, P(ws) if ws_bytes else None, ws_bytes, st))
+        got = out[:, 16:64].float()
+        err = (got - want).abs().max().item()
+        assert err <= 6e-3 * want.abs().max().item(), (ws_bytes, err, want.abs().max().item())
+        assert torch.isnan(out[:, :16].float()).all() and torch.isnan(out[:, 64:].float()).all()
+        outs.append(out[:, 16:64].clone())
+        if ws_bytes:                                             # the tile counters are left at zero
+            assert int(ws[:16384].view(torch.int32).abs().sum().item()) == 0
+    out2 = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=dev)  # same bits on a second run of the split path
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.rdm_conv3x3_act_bf16(P(Y), ldy, Cp, P(wimg), C.c_void_p(out2.data_ptr() + 2 * 16), ldc, B, H, W, P(ws), wsb, st))
+    assert torch.equal(out2[:, 16:64].view(torch.int16), outs[1].view(torch.int16))
+    assert any(k.startswith("conv3x3_act_bf16_kernel/") for k in _lib.census())
