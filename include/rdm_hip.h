@@ -157,12 +157,16 @@ int rdm_unpack_conv_weight(const float* w_packed, float* w_oihw, int32_t out_c, 
  *                     workspace (optional f32 scratch, 256-byte aligned, up to 8*M*N floats are used): lets a few-row / long-K product
  *                     (M <= 1024) split K over the grid; partial sums are reduced in a fixed order (deterministic).
  *   rdm_conv3x3_bf16  3x3 / stride 1 / pad 1 conv with 48 outputs: y (B,H,W, ldy) bf16 with the BN-ReLU prologue over its `channels`
- *                     (multiple of 8), w [9][48][channels] bf16, out (B*H*W, ldc) bf16 - typically a 48-channel slice of a wider buffer.
+ *                     (multiple of 8; scale = shift = NULL: y is already activated), w [9][48][channels] bf16, out (B*H*W, ldc) bf16 - typically a 48-channel slice of a wider buffer.
  *                     workspace (optional, 256-byte aligned): f32 scratch for a K-split that fills the chip when B*H*W is small -
  *                     partial sums are stored per split and reduced in a fixed order (deterministic); any size is accepted, the split is
  *                     sized to it (rdm_conv3x3_bf16_workspace_bytes gives the amount the heuristic would like). */
 int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* bias,
                   void* out, int32_t ldc, int32_t m, int32_t n, int32_t out_f32, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+/* rdm_gemm_bf16 with the CONSUMER's eval-mode BatchNorm + ReLU in the epilogue: out = bf16(relu(acc * out_scale[n] + out_shift[n])) - the
+ * dense layer's 1x1 in rdm_net_forward_bf16 (the 3x3 behind it then reads an already activated tensor: rdm_conv3x3_act_bf16). */
+int rdm_gemm_bf16_act(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* out_scale,
+                      const float* out_shift, void* out, int32_t ldc, int32_t m, int32_t n, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w);
 int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* scale, const float* shift, const void* w_packed, void* out,
                      int32_t ldc, int32_t batch, int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream);

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "rdm_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_unpack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_gemm_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "rdm_gemm_bf16_act": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "rdm_conv3x3_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "rdm_conv3x3_bf16": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "rdm_conv3x3_act_bf16_weight_bytes": (sz, [i32]),

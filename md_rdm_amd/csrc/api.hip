@@ -285,6 +285,16 @@ int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, con
   return launch_gemm_bf16(a, out_f32 != 0, stream);
 }
 
+int rdm_gemm_bf16_act(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* out_scale,
+                      const float* out_shift, void* out, int32_t ldc, int32_t m, int32_t n, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  RDM_CHECK_ARG(x && w && out && out_scale && out_shift && m > 0 && n > 0 && k > 0 && ldx >= k && ldw >= k && ldc >= n, "gemm_bf16_act: bad argument");
+  RDM_CHECK_ARG(!workspace || ((uintptr_t)workspace & 255) == 0, "gemm_bf16_act: workspace must be 256-byte aligned");
+  GemmBf16Args a{};
+  a.X = x; a.ldx = ldx; a.K = k; a.scale = scale; a.shift = shift; a.W = w; a.ldw = ldw; a.oscale = out_scale; a.oshift = out_shift; a.out = out; a.ldc = ldc; a.M = m; a.N = n;
+  a.partial = static_cast<float*>(workspace); a.partial_floats = workspace ? workspace_bytes / sizeof(float) : 0;
+  return launch_gemm_bf16(a, false, stream);
+}
+
 size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w) {
   if (channels <= 0 || batch <= 0 || h <= 0 || w <= 0) return 0;
   const long M = (long)batch * h * w;
@@ -295,7 +305,7 @@ size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t
 int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* scale, const float* shift, const void* w_packed, void* out,
                      int32_t ldc, int32_t batch, int32_t h, int32_t w, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
   RDM_CHECK_ARG(!workspace || ((uintptr_t)workspace & 255) == 0, "conv3x3_bf16: workspace must be 256-byte aligned");
-  RDM_CHECK_ARG(y && w_packed && out && scale && shift && batch > 0 && h > 0 && w > 0 && channels > 0 && ldy >= channels && ldc >= 48, "conv3x3_bf16: bad argument");
+  RDM_CHECK_ARG(y && w_packed && out && (scale == nullptr) == (shift == nullptr) && batch > 0 && h > 0 && w > 0 && channels > 0 && ldy >= channels && ldc >= 48, "conv3x3_bf16: bad argument");
   RDM_CHECK_ARG((long)batch * h * w < (1L << 30), "conv3x3_bf16: too many pixels for 32-bit indices");
   Conv3Bf16Args a{};
   a.Y = y; a.ldy = ldy; a.C = channels; a.scale = scale; a.shift = shift; a.Wt = w_packed; a.wtap = 48L * channels; a.ldw = channels;

@@ -9,6 +9,7 @@ struct GemmBf16Args {        // out[m][n] = bias[n] + sum_k f(X[m][k]) * W[n][k]
   const void* W; int ldw;                  // bf16 weights [N][ldw]
   void* out; int ldc; int M, N;            // bf16 (or f32) [M][ldc]
   const float* bias;                       // optional f32[N]
+  const float* oscale; const float* oshift; // optional f32[N]: out = relu(out*oscale[n] + oshift[n]) before the bf16 rounding (the CONSUMER's eval-mode BatchNorm + ReLU)
   float* partial; size_t partial_floats;   // optional f32 scratch for a K-split ([split][M][N] partial sums + one tiny reduction launch)
   unsigned x_bytes, w_bytes, p_bytes;      // set by the launcher (buffer descriptors)
 };
@@ -41,10 +42,11 @@ int launch_gemm_bf16(const GemmBf16Args& a, bool out_f32, hipStream_t s);
 int launch_conv3x3_act_bf16(const Conv3ActArgs& a, hipStream_t s);      // RDM_ERR_UNSUPPORTED when the geometry does not fit the LDS (nothing launched)
 size_t conv3x3_act_partial_floats(int C, int B, int H, int W);          // scratch the heuristic would like
 int conv3x3_act_tiles(int B, int H, int W);                             // upper bound of the tile count (counters needed)
+bool conv3x3_act_fits(int B, int H, int W);                             // a tile's padded rows fit the LDS image
 int launch_pack_w3_frag_bf16(const float* w, void* img, int C, int Cpad, int packed, hipStream_t s);
 int launch_conv3x3_bf16(const Conv3Bf16Args& a, hipStream_t s);
 int launch_f32_to_bf16_rows(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, int cols_pad, hipStream_t s);
-int launch_pack_w_bf16(const float* w_oihw, void* w_packed, int O, int I, int T, hipStream_t s);
+int launch_pack_w_bf16(const float* w_oihw, void* w_packed, int O, int I, int ld, int T, hipStream_t s);
 int launch_im2col_stem_bf16(const float* x, void* patches, int B, int H, int W, hipStream_t s);
 int launch_maxpool3s2_bf16(const void* X, void* Y, int ldy, int B, int H, int W, int C, hipStream_t s);
 int launch_trans_pool_bf16(const void* X, int ldx, const float* sc, const float* sh, void* P, int B, int H, int W, int C, hipStream_t s);

@@ -17,6 +17,7 @@
 // for the 16-lane groups the hardware forms (MI355X_MICROARCH.md, LDS): 128-byte rows: chunk ^= (row >> 1) & 7;
 // 64-byte rows read at arbitrary row offsets (halo taps): chunk ^= ((row >> 2) & 1) << 1   (both checked exhaustively).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "rdm_common.h"
@@ -210,13 +211,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wcol + j * 16 + g * 4;
     if (n >= p.N) continue;                                            // N is a multiple of 4
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), os = make_float4(1.f, 1.f, 1.f, 1.f), oh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    const bool oact = p.oscale != nullptr;
+    if (oact) { os = *reinterpret_cast<const float4*>(p.oscale + n); oh = *reinterpret_cast<const float4*>(p.oshift + n); }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wrow + i * 16 + l16;
       if (m >= p.M) continue;
-      const float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      if (oact) { v0 = fmaxf(fmaf(v0, os.x, oh.x), 0.f); v1 = fmaxf(fmaf(v1, os.y, oh.y), 0.f); v2 = fmaxf(fmaf(v2, os.z, oh.z), 0.f); v3 = fmaxf(fmaf(v3, os.w, oh.w), 0.f); }
       if (OUT_F32) {
         *reinterpret_cast<float4*>(static_cast<float*>(p.out) + (long)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
       } else {
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
   }
   uint4 rh[HL], rw[WLN];
   float4 sa, sb, ta, tb;
+  const bool bn = p.scale != nullptr;                                 // NULL: the input is already activated (the producer's epilogue did it)
   auto load_slab = [&](int cs) {
     const unsigned cb = (unsigned)(cs * CS * 2);
     // bottleneck widths are 48 * odd: the last slab holds 16 channels.  Chunks past C are forced to zero on BOTH operands (the
@@ -311,14 +316,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
     for (int i = 0; i < HL; ++i) rh[i] = bld(srdY, (kok && hoff[i] != OOB) ? hoff[i] + cb : OOB);
 #pragma unroll
     for (int i = 0; i < WLN; ++i) rw[i] = bld(srdW, (kok && woff[i] != OOB) ? woff[i] + cb : OOB);
-    const unsigned po = kok ? (unsigned)((cs * CS + ch * 8) * 4) : OOB;
-    sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
-    ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+    if (bn) {
+      const unsigned po = kok ? (unsigned)((cs * CS + ch * 8) * 4) : OOB;
+      sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
+      ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+    }
   };
   auto store_slab = [&]() {
 #pragma unroll
     for (int i = 0; i < HL; ++i)
-      if (hoff[i] != OOB) *reinterpret_cast<uint4*>(Ah + hlds[i]) = bnrelu8(rh[i], sa, sb, ta, tb);      // real pixels only: pads stay zero
+      if (hoff[i] != OOB) *reinterpret_cast<uint4*>(Ah + hlds[i]) = bn ? bnrelu8(rh[i], sa, sb, ta, tb) : rh[i];      // real pixels only: pads stay zero
 #pragma unroll
     for (int i = 0; i < WLN; ++i) {
       const int row = (tid + 256 * i) >> 2;
@@ -387,16 +394,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 / 48 outputs on an ALREADY ACTIVATED input (the producing 1x1 applied BatchNorm + ReLU in its epilogue:
-// eval mode knows the affine ahead of time), both operands by LDS-DMA.
+// eval mode knows the affine ahead of time), both operands by LDS-DMA, loader / consumer wave specialisation.
 //   * no prologue  => no staging registers, no BN-ReLU VALU work, no ds_write: `buffer_load_dwordx4 ... lds` moves 1-KiB pieces
 //     (64 lanes x 16 B) straight into the LDS image; zero padding = out-of-range source offsets (the DMA writes zeros);
-//   * a workgroup of NW wave64s owns BM = NW*64 consecutive pixels of ONE image (tiles never straddle images), every wave a
-//     64 x 48 output tile (48 accumulator registers); per 32-channel slab it needs the zero-padded image rows of the tile
-//     ([slot][32 ch] bf16, 16-byte chunks XOR-swizzled on the SOURCE side as in conv3x3_bf16_kernel) and the slab's weights in
-//     MFMA-FRAGMENT order ([tap][n-tile][lane][8 bf16]: one 1-KiB piece per fragment, read back conflict-free at lane*16);
-//   * 2 stages (image + 27 KiB of weights each), ONE barrier per slab: wait own DMAs -> barrier -> issue slab s+1 -> 108 MFMAs;
-//   * K-split over grid.y: partial sums to f32 slabs; the LAST workgroup of a tile to arrive (agent-scope counter behind
-//     __threadfence) adds them in ascending split order - no second launch, no atomics on data, same bits every run.
+//   * a workgroup = NC consumer waves + NC loader waves (one of each per SIMD at NC = 4) and owns BM = NC*128 consecutive pixels of
+//     ONE image (tiles never straddle images).  A consumer holds a 128 x 48 output tile (96 accumulator registers) and does nothing
+//     but ds_read_b128 + MFMA; a loader does nothing but issue DMAs (an LDS-DMA costs its wave 60-180 issue cycles - measured: with
+//     every wave loading AND multiplying the two costs added up, 3.0 us per slab where the MFMAs alone take 2.1);
+//   * per 32-channel slab: the zero-padded image rows of the tile ([slot][32 ch] bf16, 16-byte chunks XOR-swizzled on the SOURCE
+//     side as in conv3x3_bf16_kernel) and the slab's weights in MFMA-FRAGMENT order ([tap][n-tile][lane][8 bf16]: one 1-KiB piece
+//     per fragment, read back conflict-free at lane*16);
+//   * 2 stages at FIXED LDS offsets (image 0 | image 1 | weights 0 | weights 1 = 159 KB: the stage is an instruction immediate),
+//     ONE barrier per slab: loaders wait for their DMAs -> barrier -> loaders issue slab s+1, consumers multiply slab s;
+//   * K-split over grid.y: partial sums to f32 slabs; the LAST workgroup of a tile to arrive (device-scope ticket) adds them in
+//     ascending split order - no second launch, no atomics on data, same bits every run.
 // C must be a multiple of 32 (the network pads its bottleneck widths; pad channels are zero on both operands).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned char* lds_dst) {
@@ -405,116 +416,155 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
 #endif
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_act_bf16_kernel(Conv3ActArgs p) {
-  constexpr int MT = 4, NT = 3, BM = NW * 64, HP = 8, WPIECES = 27, WBYTES = WPIECES * 1024, NTHR = NW * 64;
+constexpr int ACT_IMG_BYTES = 52 * 1024, ACT_W_BYTES = 27 * 1024, ACT_MAX_SLOTS = ACT_IMG_BYTES / 64;     // 832 padded pixels
+constexpr int ACT_LDS_BYTES = 2 * (ACT_IMG_BYTES + ACT_W_BYTES);
+
+template <int NC>
+__global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActArgs p) {
+  constexpr int MT = 8, NT = 3, BM = NC * 128, WPIECES = 27, NTHR = NC * 128;
+  constexpr int HP = (ACT_MAX_SLOTS / 16 + NC - 1) / NC;              // image pieces per loader wave (13 at NC = 4)
+  constexpr int WP = (WPIECES + NC - 1) / NC;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int stage_bytes = p.slots * 64 + WBYTES;                     // image, then the weight fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;   // (uniform: LDS-DMA targets go to M0)
   const int W = p.W, H = p.H, Wp = W + 2, HW = H * W;
   const int tile = blockIdx.x, b = tile / p.tiles_per_img, t = tile - b * p.tiles_per_img;
   const int ml0 = t * BM, mlN = min(HW, ml0 + BM);                    // this tile's pixels inside image b
   const int y0 = ml0 / W, y1 = (mlN - 1) / W;
-  const int nslots = (y1 - y0 + 3) * Wp, npieces = (nslots + 15) >> 4;   // padded rows y0-1 .. y1+1; <= p.slots / 16 (launcher)
-  const __amdgpu_buffer_rsrc_t srdY = srd(p.Y, p.y_bytes), srdW = srd(p.Wimg, p.w_bytes);
-
-  // image pieces of this wave: piece q = wave + i*NW covers slots 16q .. 16q+15; lane -> (slot, LDS chunk); the SOURCE chunk is swizzled
-  unsigned voff[HP];
-#pragma unroll
-  for (int i = 0; i < HP; ++i) {
-    const int sl = (wave + i * NW) * 16 + (lane >> 2), c = (lane & 3) ^ (((sl >> 2) & 1) << 1);
-    const int prow = sl / Wp, x = sl - prow * Wp - 1, y = y0 - 1 + prow;
-    const bool ok = sl < nslots && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    voff[i] = ok ? (unsigned)((b * H + y) * W + x) * (unsigned)(p.ldy * 2) + (unsigned)(c * 16) : OOB;
-  }
-  const unsigned wvoff = (unsigned)(lane * 16);
-  auto issue = [&](int st, int cs) {
-    unsigned char* const base = smem + st * stage_bytes;
-    const unsigned so = (unsigned)cs * 64u;
-#ifdef RDM_DEV_VARIANTS
-    if (!(p.abl & 1))
-#endif
-#pragma unroll
-    for (int i = 0; i < HP; ++i)
-      if (wave + i * NW < npieces) dma16(srdY, voff[i], so, base + (wave + i * NW) * 1024);
-    unsigned char* const wb = base + p.slots * 64;
-    const unsigned wso = (unsigned)cs * (unsigned)WBYTES;
-#ifdef RDM_DEV_VARIANTS
-    if (!(p.abl & 2))
-#endif
-#pragma unroll
-    for (int q = 0; q < (WPIECES + NW - 1) / NW; ++q)
-      if (wave + q * NW < WPIECES) dma16(srdW, wvoff + (unsigned)((wave + q * NW) * 1024), wso, wb + (wave + q * NW) * 1024);
-  };
-
-  // LDS byte address (inside a stage) of the activation fragment of (m-tile i, tap): slot of the lane's pixel shifted by the tap
-  const bool active = ml0 + wave * 64 < mlN;                          // ragged last tile of an image: idle waves only stage and synchronise
-  unsigned faddr[MT][9];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int ml = min(ml0 + wave * 64 + i * 16 + l16, mlN - 1);     // rows past the tile are never stored: any in-range address will do
-    const int y = ml / W, x = ml - y * W;
-    const int sc = (y - y0 + 1) * Wp + x + 1;
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int sl = sc + (tp / 3 - 1) * Wp + (tp % 3 - 1);
-      faddr[i][tp] = (unsigned)(sl * 64 + ((g ^ (((sl >> 2) & 1) << 1)) << 4));
-    }
-  }
+  const int nslots = (y1 - y0 + 3) * Wp, npieces = (nslots + 15) >> 4;   // padded rows y0-1 .. y1+1; <= ACT_MAX_SLOTS / 16 (launcher)
+  const int ncs_all = p.C >> 5, split = (int)gridDim.y;
+  const int per = (ncs_all + split - 1) / split;
+  const int cs0 = blockIdx.y * per, cs1 = min(ncs_all, cs0 + per);   // the launcher leaves no split empty
+  const bool loader = wave >= NC;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ncs_all = p.C >> 5, split = (int)gridDim.y;
-  const int per = (ncs_all + split - 1) / split;
-  const int cs0 = blockIdx.y * per, cs1 = min(ncs_all, cs0 + per);   // the launcher leaves no split empty
-  issue(0, cs0);
-  for (int cs = cs0; cs < cs1; ++cs) {
-    const int st = (cs - cs0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of slab cs have landed (nothing younger is in flight)
-    __builtin_amdgcn_s_barrier();                                     // ... and everybody's; every wave is past its reads of the other stage
-    asm volatile("" ::: "memory");
-    if (cs + 1 < cs1) issue(st ^ 1, cs + 1);
+  if (loader) {
+    const int lw = wave - NC;
+    const __amdgpu_buffer_rsrc_t srdY = srd(p.Y, p.y_bytes), srdW = srd(p.Wimg, p.w_bytes);
+    // image pieces of this wave: piece q = lw + i*NC covers slots 16q .. 16q+15; lane -> (slot, LDS chunk); the SOURCE chunk is swizzled
+    unsigned voff[HP];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+      const int sl = (lw + i * NC) * 16 + (lane >> 2), c = (lane & 3) ^ (((sl >> 2) & 1) << 1);
+      const int prow = sl / Wp, x = sl - prow * Wp - 1, y = y0 - 1 + prow;
+      const bool ok = sl < nslots && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      voff[i] = ok ? (unsigned)((b * H + y) * W + x) * (unsigned)(p.ldy * 2) + (unsigned)(c * 16) : OOB;
+    }
+    const unsigned wvoff = (unsigned)(lane * 16);
+    auto issue = [&](int st, int cs) {
+      unsigned char* const ib = smem + st * ACT_IMG_BYTES;
+      unsigned char* const wb = smem + 2 * ACT_IMG_BYTES + st * ACT_W_BYTES;
+      const unsigned so = (unsigned)cs * 64u, wso = (unsigned)cs * (unsigned)ACT_W_BYTES;
 #ifdef RDM_DEV_VARIANTS
-    if (active && !(p.abl & 4)) {
-#else
-    if (active) {
+      if (!(p.abl & 1))
 #endif
-      // fragments of tap t+1 are read while the 12 MFMAs of tap t run (two register sets; the scheduler is pinned, it would otherwise
-      // fold both sets into one and wait for every read)
-      const unsigned char* const ib = smem + st * stage_bytes;
-      const unsigned char* const wb = ib + p.slots * 64 + lane * 16;
-      bf16x8 wf[2][NT], xf[2][MT];
-      auto frags = [&](int set, int tp) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(wb + (tp * 3 + j) * 1024);
+      for (int i = 0; i < HP; ++i)
+        if (lw + i * NC < npieces) dma16(srdY, voff[i], so, ib + (lw + i * NC) * 1024);
+#ifdef RDM_DEV_VARIANTS
+      if (!(p.abl & 2))
+#endif
 #pragma unroll
-        for (int i = 0; i < MT; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(ib + faddr[i][tp]);
-      };
-      frags(0, 0);
+      for (int q = 0; q < WP; ++q)
+        if (lw + q * NC < WPIECES) dma16(srdW, wvoff + (unsigned)((lw + q * NC) * 1024), wso, wb + (lw + q * NC) * 1024);
+    };
+    issue(0, cs0);
+    for (int cs = cs0; cs < cs1; ++cs) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's pieces of slab cs have landed (nothing younger is in flight)
+      __builtin_amdgcn_s_barrier();                                   // ... and everybody's; the consumers are past their reads of the other stage
+      asm volatile("" ::: "memory");
+      if (cs + 1 < cs1) issue(((cs - cs0) & 1) ^ 1, cs + 1);
+    }
+  } else {
+    // LDS address (stage 0, in 16-byte units: 13 bits) of the activation fragment of (m-tile i, tap): slot of the lane's pixel shifted
+    // by the tap; two taps per register (96 accumulators + 72 full addresses + the fragment sets would spill), unpacked by one
+    // shift-of-a-halfword per read
+    unsigned fpk[MT][5];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ml = min(ml0 + wave * 128 + i * 16 + l16, mlN - 1);   // rows past the tile are never stored: any in-range address will do
+      const int y = ml / W, x = ml - y * W;
+      const int sc = (y - y0 + 1) * Wp + x + 1;
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
-        if (tp < 8) frags((tp + 1) & 1, tp + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        const int sl = sc + (tp / 3 - 1) * Wp + (tp % 3 - 1);
+        const unsigned a16 = (unsigned)(sl * 4 + (g ^ (((sl >> 2) & 1) << 1)));
+        if (tp & 1) fpk[i][tp >> 1] |= a16 << 16; else fpk[i][tp >> 1] = a16;
+      }
+    }
+    const bool active = ml0 + wave * 128 < mlN;                       // ragged last tile of an image: idle consumers only synchronise
+    // one slab from the stage at compile-time LDS offsets: 18 steps (tap, half of the 8 m-tiles) of 12 MFMAs; the fragments of step
+    // k+1 are read while step k multiplies (two register sets; the scheduler is pinned, it would otherwise fold the sets and wait on every read)
+    auto slab = [&](auto stc) {
+      constexpr int ST = decltype(stc)::value;
+      const unsigned char* const ib = smem + ST * ACT_IMG_BYTES;
+      const unsigned char* const wb = smem + 2 * ACT_IMG_BYTES + ST * ACT_W_BYTES + lane * 16;
+      bf16x8 wf[2][NT], xf[2][4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp & 1][j], xf[tp & 1][i], acc[i][j], 0, 0, 0);
+        for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(fpk[i][q]));   // (keeps the 72 unpacked addresses from being hoisted out of the slab loop into registers)
+      auto wfrags = [&](int set, int tp) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(wb + (tp * 3 + j) * 1024);
+      };
+      auto xfrags = [&](int set, int tp, int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(ib + (((fpk[h * 4 + i][tp >> 1] >> ((tp & 1) * 16)) & 0xFFFFu) << 4));
+      };
+      wfrags(0, 0); xfrags(0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        const int tp = k >> 1, h = k & 1;
+        if (k < 17) {
+          if (h == 1) wfrags((tp + 1) & 1, tp + 1);
+          xfrags((k + 1) & 1, (k + 1) >> 1, (k + 1) & 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp & 1][j], xf[k & 1][i], acc[h * 4 + i][j], 0, 0, 0);
+        // one wave per SIMD: the next step's address unpacks and fragment reads go BETWEEN this step's MFMAs (an MFMA holds the
+        // vector issue for half of its 16 cycles; issued as a block in front they cost 0.8 us per slab of MFMA idle time)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#ifdef RDM_DEV_VARIANTS
+    const bool work = active && !(p.abl & 4);
+#else
+    const bool work = active;
+#endif
+    for (int cs = cs0; cs < cs1; cs += 2) {                            // stages alternate in straight-line code (accumulation stays in place)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (work) slab(std::integral_constant<int, 0>{});
+      if (cs + 1 < cs1) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (work) slab(std::integral_constant<int, 1>{});
       }
     }
   }
+
   const long pix0 = (long)b * HW + ml0;
+  const bool store = !loader && ml0 + wave * 128 < mlN;
   if (split == 1) {
-    if (!active) return;
+    if (!store) return;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = j * 16 + g * 4;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int r = wave * 64 + i * 16 + l16;
+        const int r = wave * 128 + i * 16 + l16;
         if (ml0 + r < mlN)
           *reinterpret_cast<uint2*>(p.out + (pix0 + r) * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
       }
@@ -527,21 +577,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_act_bf16_kernel(Conv3ActAr
   // go through to the memory side; ordering = this wave's stores acknowledged (vmcnt(0)) -> workgroup barrier -> ticket (device-scope
   // atomic at the memory side) -> the last workgroup's sc1 loads.
   const __amdgpu_buffer_rsrc_t srdP = srd(p.partial + (size_t)tile * split * (size_t)(BM * 48), (unsigned)(split * BM * 48 * 4));
-  if (active) {
+  if (store) {
     const unsigned mine = (unsigned)blockIdx.y * (unsigned)(BM * 48 * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = j * 16 + g * 4;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int r = wave * 64 + i * 16 + l16;
+        const int r = wave * 128 + i * 16 + l16;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), srdP, (int)(mine + (unsigned)(r * 48 + n) * 4u), 0, 16);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  volatile int* const flag = reinterpret_cast<volatile int*>(smem);   // every wave is past its last fragment read
+  int* const flag = reinterpret_cast<int*>(smem);                     // every wave is past its last fragment read
   if (tid == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = ticket == (unsigned)(split - 1);
@@ -552,7 +602,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_act_bf16_kernel(Conv3ActAr
   // every thread owns 12 float4 of the tile (BM*12 / NTHR); a slab element comes from the memory side (~1.5 us): all loads of 6
   // elements x 6 slabs are issued before the first add - 2 round trips for a split <= 6 instead of 12 x split
   const int nrow = mlN - ml0;
-  constexpr int G = 6, ZB = 6;
+  constexpr int G = 6, ZB = 5;
 #pragma unroll
   for (int k0 = 0; k0 < 12; k0 += G) {
     f32x4 a[G];
@@ -600,7 +650,8 @@ __global__ __launch_bounds__(256) void k_pack_w3_frag_bf16(const float* __restri
 }
 
 // out[m][n .. n+3] = bf16(sum_s partial[s][m][n .. n+3]) in a fixed order (s ascending): the reduction of the K-split
-__global__ __launch_bounds__(256) void k_reduce_partials_bf16(const float* __restrict__ partial, int split, long MN4, int n4, unsigned short* __restrict__ out, int ldc) {
+__global__ __launch_bounds__(256) void k_reduce_partials_bf16(const float* __restrict__ partial, int split, long MN4, int n4, unsigned short* __restrict__ out, int ldc,
+                                                              const float* __restrict__ oscale, const float* __restrict__ oshift) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
     float4 a = *reinterpret_cast<const float4*>(partial + i * 4);
     for (int s = 1; s < split; ++s) {
@@ -608,6 +659,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials_bf16(const float* __res
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     const long m = i / n4; const int n = (int)(i - m * n4) * 4;
+    if (oscale) {
+      const float4 os = *reinterpret_cast<const float4*>(oscale + n), oh = *reinterpret_cast<const float4*>(oshift + n);
+      a.x = fmaxf(fmaf(a.x, os.x, oh.x), 0.f); a.y = fmaxf(fmaf(a.y, os.y, oh.y), 0.f); a.z = fmaxf(fmaf(a.z, os.z, oh.z), 0.f); a.w = fmaxf(fmaf(a.w, os.w, oh.w), 0.f);
+    }
     *reinterpret_cast<uint2*>(out + m * ldc + n) = make_uint2(pack2(a.x, a.y), pack2(a.z, a.w));
   }
 }
@@ -623,13 +678,13 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16_rows(const float* __restric
     dst[r * ldd + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
   }
 }
-// [O][I][T] (PyTorch OIHW, T = kh*kw) -> [T][O][I] bf16
-__global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ w, unsigned short* __restrict__ wp, int O, int I, int T) {
+// [O][I][T] (PyTorch OIHW, T = kh*kw) -> [T][O][ld] bf16 (columns I .. ld-1 are left alone: the caller zeroed them)
+__global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ w, unsigned short* __restrict__ wp, int O, int I, int ld, int T) {
   const long total = (long)T * O * I;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % I); const long t = i / I;
     const int o = (int)(t % O), tap = (int)(t / O);
-    wp[i] = __builtin_bit_cast(unsigned short, (__bf16)w[((long)o * I + c) * T + tap]);
+    wp[t * ld + c] = __builtin_bit_cast(unsigned short, (__bf16)w[((long)o * I + c) * T + tap]);
   }
 }
 // im2col of the 7x7/s2/p3 stem (RDM_Net.py:524): patches[m][k], k = c*49 + r*7 + s, zero for k >= 147, row length 160, bf16
@@ -723,9 +778,9 @@ int launch_f32_to_bf16_rows(const float* src, int ld_src, void* dst, int ld_dst,
   RDM_LAUNCH_OK();
   return 0;
 }
-int launch_pack_w_bf16(const float* w, void* wp, int O, int I, int T, hipStream_t s) {
+int launch_pack_w_bf16(const float* w, void* wp, int O, int I, int ld, int T, hipStream_t s) {
   const long total = (long)T * O * I;
-  hipLaunchKernelGGL(k_pack_w_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, w, static_cast<unsigned short*>(wp), O, I, T);
+  hipLaunchKernelGGL(k_pack_w_bf16, dim3((unsigned)std::min<long>(cdiv(total, 256), 8192)), dim3(256), 0, s, w, static_cast<unsigned short*>(wp), O, I, ld, T);
   RDM_LAUNCH_OK();
   return 0;
 }
@@ -759,6 +814,7 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   RDM_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0, "gemm_bf16: N (%d) and ldc must be multiples of 4", a.N);
   RDM_CHECK_ARG((((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)a.out) & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
   RDM_CHECK_ARG((a.scale == nullptr) == (a.shift == nullptr) && (((uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.bias) & 15) == 0, "gemm_bf16: bad prologue / bias pointers");
+  RDM_CHECK_ARG((a.oscale == nullptr) == (a.oshift == nullptr) && (((uintptr_t)a.oscale | (uintptr_t)a.oshift) & 15) == 0 && !(a.oscale && out_f32), "gemm_bf16: bad output-activation pointers");
   const long xb = ((long)(a.M - 1) * a.ldx + a.K) * 2, wb = ((long)(a.N - 1) * a.ldw + a.K) * 2;
   if (xb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("gemm_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.K * 4);
@@ -790,7 +846,7 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   if (split > 1) {
     const long mn4 = (long)a.M * a.N / 4;
     hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, a.N / 4,
-                       static_cast<unsigned short*>(a.out), a.ldc);
+                       static_cast<unsigned short*>(a.out), a.ldc, a.oscale, a.oshift);
   }
 #undef RDM_G
   profile_end(tk, s);
@@ -802,7 +858,7 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
   Conv3Bf16Args a = a_in;
   RDM_CHECK_ARG(a.C > 0 && a.C % 8 == 0 && a.ldy % 8 == 0 && a.ldw % 8 == 0 && a.wtap % 8 == 0 && a.ldc % 4 == 0, "conv3x3_bf16: C (%d) and the strides must be multiples of 8", a.C);
   RDM_CHECK_ARG((((uintptr_t)a.Y | (uintptr_t)a.Wt | (uintptr_t)a.scale | (uintptr_t)a.shift) & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "conv3x3_bf16: operands must be 16-byte aligned");
-  RDM_CHECK_ARG(a.scale && a.shift && a.M == a.B * a.H * a.W, "conv3x3_bf16: needs the BN-ReLU prologue; M must be B*H*W");
+  RDM_CHECK_ARG((a.scale == nullptr) == (a.shift == nullptr) && a.M == a.B * a.H * a.W, "conv3x3_bf16: scale and shift come together; M must be B*H*W");
   const long yb = ((long)(a.M - 1) * a.ldy + a.C) * 2, wb = (8L * a.wtap + 47L * a.ldw + a.C) * 2;
   if (yb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("conv3x3_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
   a.y_bytes = (unsigned)yb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.C * 4);
@@ -860,7 +916,7 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
 #undef RDM_C3
   if (split > 1) {
     const long mn4 = (long)a.M * 12;
-    hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, 12, a.out, a.ldc);
+    hipLaunchKernelGGL(k_reduce_partials_bf16, dim3((unsigned)std::min<long>(cdiv(mn4, 256), 4096)), dim3(256), 0, s, a.partial, split, mn4, 12, a.out, a.ldc, nullptr, nullptr);
   }
   profile_end(tk, s);
   RDM_LAUNCH_OK();
@@ -870,36 +926,33 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
 
 // ---- conv3x3_act_bf16_kernel: tile / split choice ----
 namespace {
-struct Conv3ActPlan { int nw = 0, split = 1, slots = 0, tpi = 0; size_t lds = 0; double cost = 0; };
-// max zero-padded LDS slots (multiple of 16) over the tiles of one image
+struct Conv3ActPlan { int nc = 0, split = 1, tpi = 0; double cost = 0; };
+// max zero-padded LDS slots over the tiles of one image
 int act_slots(int H, int W, int bm) {
   const int HW = H * W, tpi = cdiv(HW, bm);
   int rows = 0;
   for (int t = 0; t < tpi; ++t) rows = std::max(rows, (std::min(HW, (t + 1) * bm) - 1) / W - (t * bm) / W + 3);
-  return (rows * (W + 2) + 15) & ~15;
+  return rows * (W + 2);
 }
 bool plan_conv3_act(int C, int B, int H, int W, size_t partial_floats, int n_counters, Conv3ActPlan& best) {
   const int HW = H * W, slabs = C / 32;
   best = Conv3ActPlan{};
-  for (int nw = 2; nw <= 8; ++nw) {
-    const int bm = nw * 64, tpi = cdiv(HW, bm), slots = act_slots(H, W, bm);
-    if (slots > 128 * nw) continue;                                   // 8 pieces per wave
-    const size_t lds = 2 * ((size_t)slots * 64 + 27 * 1024);
-    if (lds > 160 * 1024) continue;
+  for (int nc = 1; nc <= 4; ++nc) {
+    const int bm = nc * 128, tpi = cdiv(HW, bm);
+    if (act_slots(H, W, bm) > ACT_MAX_SLOTS) continue;
     const long tiles = (long)B * tpi;
-    const int res = (int)std::max<size_t>(1, std::min<size_t>((size_t)(8 / nw), (160 * 1024) / lds));   // workgroups per CU (2 waves per SIMD, LDS)
     for (int sp = 1; sp <= std::min(slabs, 32); ++sp) {
       const int per = cdiv(slabs, sp), spe = cdiv(slabs, per);
       if (spe != sp) continue;
       if (spe > 1 && ((size_t)tiles * spe * bm * 48 > partial_floats || tiles > n_counters)) break;
-      const long blocks = tiles * spe, rounds = cdiv(blocks, 256L * res);
-      const int wps = cdiv(nw * (int)std::min<long>(res, cdiv(blocks, 256L)), 4);      // waves sharing a SIMD
-      // microseconds: per slab 0.42 (one wave per SIMD) / 0.75 (two); prologue + epilogue 2.5; ordered combine: 2 memory round trips per 6 slabs
-      const double cost = (double)rounds * (per * (wps > 1 ? 0.75 : 0.42) + 2.5) + (spe > 1 ? 1.0 + 2 * cdiv(spe, 6) * 1.7 : 0.0);
-      if (best.nw == 0 || cost < best.cost * 0.98) { best.nw = nw; best.split = spe; best.slots = slots; best.tpi = tpi; best.lds = lds; best.cost = cost; }
+      const long blocks = tiles * spe, rounds = cdiv(blocks, 256L);          // one workgroup per CU (159 KB of LDS)
+      // microseconds.  Per slab: 216 MFMAs per consumer (1.7) or, when few workgroups run, the DMA round trip (1.2); prologue +
+      // epilogue 3; ordered combine: 2 memory round trips per 6 slabs
+      const double cost = (double)rounds * (per * 1.8 + 3.0) + (spe > 1 ? 1.0 + 2 * cdiv(spe, 6) * 1.7 : 0.0);
+      if (best.nc == 0 || cost < best.cost * 0.98) { best.nc = nc; best.split = spe; best.tpi = tpi; best.cost = cost; }
     }
   }
-  return best.nw != 0;
+  return best.nc != 0;
 }
 }  // namespace
 
@@ -909,6 +962,10 @@ size_t conv3x3_act_partial_floats(int C, int B, int H, int W) {
   return (size_t)tiles * 128 * 48 * (size_t)std::min(std::max(C / 64, 1), 8) + (size_t)B * 8 * 512 * 48;
 }
 int conv3x3_act_tiles(int B, int H, int W) { return B * cdiv(H * W, 128); }
+bool conv3x3_act_fits(int B, int H, int W) {
+  Conv3ActPlan pl;
+  return plan_conv3_act(32, B, H, W, 0, 0, pl);
+}
 
 int launch_pack_w3_frag_bf16(const float* w, void* img, int C, int Cpad, int packed, hipStream_t s) {
   RDM_CHECK_ARG(C > 0 && Cpad >= C && Cpad % 32 == 0, "pack_w3_frag_bf16: padded channel count (%d) must be a multiple of 32 >= %d", Cpad, C);
@@ -932,24 +989,24 @@ int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
     set_error("conv3x3_act_bf16: rows of %d pixels do not fit the LDS image", a.W);
     return RDM_ERR_UNSUPPORTED;
   }
-  a.split = pl.split; a.slots = pl.slots; a.tiles_per_img = pl.tpi;
+  a.split = pl.split; a.slots = ACT_MAX_SLOTS; a.tiles_per_img = pl.tpi;
 #ifdef RDM_DEV_VARIANTS
   a.abl = g_variant >= 100 && g_variant < 116 ? g_variant - 100 : 0;
 #endif
   void* tk = profile_begin(s, 2.0 * M * 48.0 * a.C * 9.0, 8, 2.0 * ((double)M * a.C + 9.0 * 48 * a.C + (double)M * 48));
   dim3 grid((unsigned)(a.B * pl.tpi), (unsigned)pl.split);
-#define RDM_C3A(NW_)                                                                                                                      \
-  case NW_: {                                                                                                                              \
+#define RDM_C3A(NC_)                                                                                                                      \
+  case NC_: {                                                                                                                              \
     static bool attr_set = false;                                                                                                          \
-    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_act_bf16_kernel<NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
-    hipLaunchKernelGGL((conv3x3_act_bf16_kernel<NW_>), grid, dim3(NW_ * 64), pl.lds, s, a);                                                \
+    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_act_bf16_kernel<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, ACT_LDS_BYTES)); attr_set = true; } \
+    hipLaunchKernelGGL((conv3x3_act_bf16_kernel<NC_>), grid, dim3(NC_ * 128), ACT_LDS_BYTES, s, a);                                        \
   } break
-  switch (pl.nw) {
-    RDM_C3A(2); RDM_C3A(3); RDM_C3A(4); RDM_C3A(5); RDM_C3A(6); RDM_C3A(7); RDM_C3A(8);
+  switch (pl.nc) {
+    RDM_C3A(1); RDM_C3A(2); RDM_C3A(3); RDM_C3A(4);
     default: set_error("conv3x3_act_bf16: bad plan"); return RDM_ERR_UNSUPPORTED;
   }
 #undef RDM_C3A
-  RDM_CENSUS("conv3x3_act_bf16_kernel/nw%d/%s", pl.nw, pl.split > 1 ? "splitK" : "direct");
+  RDM_CENSUS("conv3x3_act_bf16_kernel/nc%d/%s", pl.nc, pl.split > 1 ? "splitK" : "direct");
   profile_end(tk, s);
   RDM_LAUNCH_OK();
   return 0;

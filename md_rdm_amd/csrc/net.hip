@@ -190,18 +190,27 @@ struct NetImpl {
   struct Bf16Layer { size_t w1, w3, bn1, bn2; };
   std::vector<Bf16Layer> bfl[4];
   size_t bf_wt[3], bf_tbn[3], bf_stem_w, bf_head_w, bf_wtotal = 0;
-  size_t bf_patches, bf_e1, bf_blk[4], bf_Y, bf_P[3], bf_logits, bf_partial, bf_partial_floats, bf_total = 0;
+  size_t bf_patches, bf_e1, bf_blk[4], bf_Y, bf_P[3], bf_logits, bf_partial, bf_partial_floats, bf_counters, bf_total = 0;
+  int bf_cbp[4];            // bottleneck width padded to a multiple of 32 (zero weight rows / columns, zero affine: the pad channels of Y are exact zeros)
+  bool bf_act3[4];          // the block's 3x3 runs conv3x3_act_bf16_kernel (LDS-DMA, fragment-order weight image); else conv3x3_bf16_kernel without prologue
+  static constexpr int kBfCounters = 4096;
   double bf_bytes = 0;      // algorithmic HBM bytes of one bf16 forward (every activation written once, read by its consumers once; weights once)
   void plan_bf16() {
     Bump w;
     for (int b = 0; b < 4; ++b) {
+      const int cbp = (bg[b].cb + 31) / 32 * 32;
+      bf_cbp[b] = cbp;
+      // many-pixel blocks (dense_e2 / e3): the DMA kernel; few-pixel blocks are bound by launch + memory round trips, where the
+      // register-staged kernel with its separate reduction launch measured faster (bf16_microbench: 15.3 vs 19.7 us at dense_e4).
+      // By BLOCK, not by geometry: the prepared weight buffer (3x3 layout) must serve every plan of the same weights.
+      bf_act3[b] = b < 2;
       bfl[b].resize(kBlocks[b].layers);
       for (int i = 0; i < kBlocks[b].layers; ++i) {
         const int cin = kBlocks[b].cin + i * GROWTH;
-        bfl[b][i].w1 = w.take<unsigned short>((size_t)bg[b].cb * cin);
-        bfl[b][i].w3 = w.take<unsigned short>((size_t)9 * GROWTH * bg[b].cb);
+        bfl[b][i].w1 = w.take<unsigned short>((size_t)cbp * cin);
+        bfl[b][i].w3 = w.take<unsigned short>((size_t)9 * GROWTH * cbp);             // either layout: 27 KiB per 32 channels
         bfl[b][i].bn1 = w.take<float>(4 * (size_t)cin);
-        bfl[b][i].bn2 = w.take<float>(4 * (size_t)bg[b].cb);
+        bfl[b][i].bn2 = w.take<float>(4 * (size_t)cbp);
       }
     }
     for (int t = 0; t < 3; ++t) {
@@ -217,18 +226,20 @@ struct NetImpl {
     bf_e1 = a.take<unsigned short>((size_t)M1 * 96);
     for (int b = 0; b < 4; ++b) {
       bf_blk[b] = a.take<unsigned short>((size_t)bg[b].M * bg[b].ctot);
-      maxY = std::max(maxY, (size_t)bg[b].M * bg[b].cb);
+      maxY = std::max(maxY, (size_t)bg[b].M * bf_cbp[b]);
     }
     bf_Y = a.take<unsigned short>(maxY);
     for (int t = 0; t < 3; ++t) bf_P[t] = a.take<unsigned short>((size_t)bg[t + 1].M * kTrans[t].cin);
     bf_logits = a.take<float>((size_t)bg[3].M * 192);
-    bf_partial_floats = 0;                                        // K-split partial sums of the 3x3 convs: up to 24 slabs of [M][48] f32
+    bf_partial_floats = 0;                                        // K-split partial sums of the 3x3 convs
     for (int b = 0; b < 4; ++b) {
-      const int split = std::min(std::max(cdiv(bg[b].cb, 32) / 2, 1), 16);       // the launcher sizes the split to what it is given
+      if (bf_act3[b]) { bf_partial_floats = std::max(bf_partial_floats, conv3x3_act_partial_floats(bf_cbp[b], B, bg[b].H, bg[b].W)); continue; }
+      const int split = std::min(std::max(cdiv(bf_cbp[b], 32) / 2, 1), 16);       // the launcher sizes the split to what it is given
       bf_partial_floats = std::max(bf_partial_floats, (size_t)split * bg[b].M * GROWTH);
     }
-    bf_partial_floats = std::max(bf_partial_floats, (size_t)8 * bg[3].M * bg[3].cb);      // K-split of the decoder's 1x1 convs
+    bf_partial_floats = std::max(bf_partial_floats, (size_t)8 * bg[3].M * bf_cbp[3]);      // K-split of the decoder's 1x1 convs
     bf_partial = a.take<float>(bf_partial_floats);
+    bf_counters = a.take<unsigned>(kBfCounters);
     bf_total = (a.off + 255) & ~(size_t)255;
     // algorithmic traffic: x (f32) + patches w+r + e1 w+r + per layer [prefix read + Y write + Y read + 48-slice write] + transitions + head
     double by = (double)B * 3 * H0 * W0 * 4 + 2.0 * M1 * 160 * 2 + 2.0 * M1 * 96 * 2 + (double)bg[0].M * 96 * 2;
@@ -861,24 +872,26 @@ int rdm_net_bf16_prepare(rdm_net* net, void* const* T, void* wbuf, size_t wbuf_b
     RDM_CHECK_ARG(T[i] != nullptr || reg().t[i].numel == 0, "tensor %d (%s) is NULL", i, reg().t[i].name.c_str());
   hipStream_t s = stream;
   int rc;
-  auto affine = [&](const BnIdx& b, size_t off, int C) {      // eval-mode BatchNorm folded to (scale, shift): running statistics
+  auto affine = [&](const BnIdx& b, size_t off, int C, int Cp) {      // eval-mode BatchNorm folded to (scale, shift): running statistics; arrays Cp long
     float* d = at<float>(wbuf, off);
-    return launch_bn_finalize(nullptr, nullptr, 1.0, F(T, b.w), F(T, b.b), F(T, b.rm), F(T, b.rv), nullptr, d, d + C, d + 2 * C, d + 3 * C, C, 0, s);
+    return launch_bn_finalize(nullptr, nullptr, 1.0, F(T, b.w), F(T, b.b), F(T, b.rm), F(T, b.rv), nullptr, d, d + Cp, d + 2 * Cp, d + 3 * Cp, C, 0, s);
   };
+  RDM_HIP_OK(hipMemsetAsync(wbuf, 0, n.bf_wtotal, s));        // the padded rows / columns / affines of the bottleneck widths are zeros
   for (int b = 0; b < 4; ++b)
     for (int i = 0; i < kBlocks[b].layers; ++i) {
       const LayerIdx& L = reg().layers[b][i];
       const NetImpl::Bf16Layer& W = n.bfl[b][i];
-      const int cin = kBlocks[b].cin + i * GROWTH, cb = n.bg[b].cb;
+      const int cin = kBlocks[b].cin + i * GROWTH, cb = n.bg[b].cb, cbp = n.bf_cbp[b];
       if ((rc = launch_f32_to_bf16_rows(F(T, L.conv1), cin, at<char>(wbuf, W.w1), cin, cb, cin, cin, s))) return rc;
-      if (n.opt_packed3x3) { if ((rc = launch_f32_to_bf16_rows(F(T, L.conv2), cb, at<char>(wbuf, W.w3), cb, 9L * GROWTH, cb, cb, s))) return rc; }
-      else if ((rc = launch_pack_w_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), GROWTH, cb, 9, s))) return rc;
-      if ((rc = affine(L.bn1, W.bn1, cin))) return rc;
-      if ((rc = affine(L.bn2, W.bn2, cb))) return rc;
+      if (n.bf_act3[b]) { if ((rc = launch_pack_w3_frag_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), cb, cbp, n.opt_packed3x3, s))) return rc; }
+      else if (n.opt_packed3x3) { if ((rc = launch_f32_to_bf16_rows(F(T, L.conv2), cb, at<char>(wbuf, W.w3), cbp, 9L * GROWTH, cb, cb, s))) return rc; }
+      else if ((rc = launch_pack_w_bf16(F(T, L.conv2), at<char>(wbuf, W.w3), GROWTH, cb, cbp, 9, s))) return rc;
+      if ((rc = affine(L.bn1, W.bn1, cin, cin))) return rc;
+      if ((rc = affine(L.bn2, W.bn2, cb, cbp))) return rc;
     }
   for (int t = 0; t < 3; ++t) {
     if ((rc = launch_f32_to_bf16_rows(F(T, reg().trans_conv[t]), kTrans[t].cin, at<char>(wbuf, n.bf_wt[t]), kTrans[t].cin, kTrans[t].cout, kTrans[t].cin, kTrans[t].cin, s))) return rc;
-    if ((rc = affine(reg().trans_bn[t], n.bf_tbn[t], kTrans[t].cin))) return rc;
+    if ((rc = affine(reg().trans_bn[t], n.bf_tbn[t], kTrans[t].cin, kTrans[t].cin))) return rc;
   }
   if ((rc = launch_f32_to_bf16_rows(F(T, reg().stem_w), 147, at<char>(wbuf, n.bf_stem_w), 160, 96, 147, 160, s))) return rc;   // K 147 -> 160, zero padded
   if ((rc = launch_f32_to_bf16_rows(F(T, reg().conv2_w), 2208, at<char>(wbuf, n.bf_head_w), 2208, 180, 2208, 2208, s))) return rc;
@@ -895,6 +908,7 @@ int rdm_net_forward_bf16(rdm_net* net, const float* x, void* const* T, const voi
   hipStream_t s = stream;
   void* wb = const_cast<void*>(wbuf);
   int rc;
+  RDM_HIP_OK(hipMemsetAsync(at<char>(ws, n.bf_counters), 0, NetImpl::kBfCounters * sizeof(unsigned), s));     // tile tickets (self-resetting; a fresh workspace is not)
   // stem: 7x7/s2 as im2col + GEMM (K = 147 padded to 160) + bias, 3x3/s2 max-pool into the first 96 channels of block 0
   if ((rc = launch_im2col_stem_bf16(x, at<char>(ws, n.bf_patches), n.B, n.H0, n.W0, s))) return rc;
   {
@@ -913,18 +927,28 @@ int rdm_net_forward_bf16(rdm_net* net, const float* x, void* const* T, const voi
       const int cin = kBlocks[b].cin + i * GROWTH;
       const float* bn1 = at<float>(wb, W.bn1);
       const float* bn2 = at<float>(wb, W.bn2);
-      GemmBf16Args a{};                                      // BN-ReLU -> 1x1 (cin -> cb)
+      const int cbp = n.bf_cbp[b];
+      GemmBf16Args a{};                                      // BN-ReLU -> 1x1 (cin -> cb) -> the 3x3's BN-ReLU in the epilogue (eval mode: known ahead)
       a.X = blk; a.ldx = g.ctot; a.K = cin; a.scale = bn1; a.shift = bn1 + cin;
       a.W = at<char>(wb, W.w1); a.ldw = cin;
-      a.out = at<char>(ws, n.bf_Y); a.ldc = g.cb; a.M = g.M; a.N = g.cb;
+      a.out = at<char>(ws, n.bf_Y); a.ldc = cbp; a.M = g.M; a.N = cbp; a.oscale = bn2; a.oshift = bn2 + cbp;
       a.partial = at<float>(ws, n.bf_partial); a.partial_floats = n.bf_partial_floats;
       if ((rc = launch_gemm_bf16(a, false, s))) return rc;
-      Conv3Bf16Args c{};                                     // BN-ReLU -> 3x3 (cb -> 48), written in place behind the block's channels
-      c.Y = at<char>(ws, n.bf_Y); c.ldy = g.cb; c.C = g.cb; c.scale = bn2; c.shift = bn2 + g.cb;
-      c.Wt = at<char>(wb, W.w3); c.wtap = (long)GROWTH * g.cb; c.ldw = g.cb;
-      c.out = blk + cin; c.ldc = g.ctot; c.B = n.B; c.H = g.H; c.W = g.W; c.M = g.M;
-      c.partial = at<float>(ws, n.bf_partial); c.partial_floats = n.bf_partial_floats;
-      if ((rc = launch_conv3x3_bf16(c, s))) return rc;
+      if (n.bf_act3[b]) {                                    // 3x3 (cb -> 48) on the activated tensor, written in place behind the block's channels
+        Conv3ActArgs c{};
+        c.Y = at<char>(ws, n.bf_Y); c.ldy = cbp; c.C = cbp; c.Wimg = at<char>(wb, W.w3);
+        c.out = blk + cin; c.ldc = g.ctot; c.B = n.B; c.H = g.H; c.W = g.W;
+        c.partial = at<float>(ws, n.bf_partial); c.partial_floats = n.bf_partial_floats;
+        c.counters = at<unsigned>(ws, n.bf_counters); c.n_counters = NetImpl::kBfCounters;
+        if ((rc = launch_conv3x3_act_bf16(c, s))) return rc;
+      } else {
+        Conv3Bf16Args c{};
+        c.Y = at<char>(ws, n.bf_Y); c.ldy = cbp; c.C = cbp;
+        c.Wt = at<char>(wb, W.w3); c.wtap = (long)GROWTH * cbp; c.ldw = cbp;
+        c.out = blk + cin; c.ldc = g.ctot; c.B = n.B; c.H = g.H; c.W = g.W; c.M = g.M;
+        c.partial = at<float>(ws, n.bf_partial); c.partial_floats = n.bf_partial_floats;
+        if ((rc = launch_conv3x3_bf16(c, s))) return rc;
+      }
     }
     if (b < 3) {
       const BlockGeom& gn = n.bg[b + 1];

@@ -203,3 +203,46 @@ def test_conv3x3_act_bf16_operator(dev, op_census, B, H, W, Cc):
     _lib.check(L.rdm_conv3x3_act_bf16(P(Y), ldy, Cp, P(wimg), C.c_void_p(out2.data_ptr() + 2 * 16), ldc, B, H, W, P(ws), wsb, st))
     assert torch.equal(out2[:, 16:64].view(torch.int16), outs[1].view(torch.int16))
     assert any(k.startswith("conv3x3_act_bf16_kernel/") for k in _lib.census())
+
+
+@pytest.mark.parametrize("M,K,N,ld_pad", [(34656, 144, 2752, 48), (2280, 1056, 736, 96), (285, 2064, 736, 48), (80, 2160, 384, 48)])
+def test_gemm_bf16_act_operator(dev, M, K, N, ld_pad):
+    """rdm_gemm_bf16_act: bf16(relu((relu(X*scale+shift) @ W^T) * out_scale + out_shift)) - the consumer's BatchNorm + ReLU applied to the
+    f32 accumulator before the single bf16 rounding; direct epilogue and (few rows) the K-split + reduction path."""
+    from md_rdm_amd import _lib
+    L, st, P = _lib.lib(), _lib.stream(), _lib.ptr
+    ldx = K + ld_pad
+    X = torch.from_numpy(U(f"ga.x{M}", (M, ldx), -2.0, 2.0)).to(dev).bfloat16()
+    Wt = torch.from_numpy(U(f"ga.w{N}", (N, K), -0.1, 0.1)).to(dev).bfloat16()
+    sc = torch.from_numpy(U("ga.sc", (K,), 0.5, 1.5)).to(dev)
+    sh = torch.from_numpy(U("ga.sh", (K,), -0.3, 0.3)).to(dev)
+    osc = torch.from_numpy(U("ga.osc", (N,), -1.5, 1.5)).to(dev)
+    osh = torch.from_numpy(U("ga.osh", (N,), -0.5, 0.5)).to(dev)
+    A = torch.relu(X[:, :K].float() * sc + sh).bfloat16().float()
+    want = torch.relu((A @ Wt.float().t()) * osc + osh)
+    ws = torch.empty(8 * M * N * 4 if M <= 1024 else 256, dtype=torch.uint8, device=dev)
+    for use_ws in (0, 1):
+        out = torch.full((M, N + 8), float("nan"), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.rdm_gemm_bf16_act(P(X), ldx, K, P(sc), P(sh), P(Wt), K, P(osc), P(osh), P(out), N + 8, M, N, P(ws) if use_ws else None, ws.numel() if use_ws else 0, st))
+        err = (out[:, :N].float() - want).abs().max().item()
+        assert err <= 6e-3 * want.abs().max().item(), (use_ws, err, want.abs().max().item())
+        assert torch.isnan(out[:, N:].float()).all()
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(1, 29, 38, 1408), (8, 15, 19, 736), (8, 8, 10, 384)])
+def test_conv3x3_bf16_operator_without_prologue(dev, B, H, W, Cc):
+    """rdm_conv3x3_bf16 with scale = shift = NULL: the input is already activated (few-pixel blocks of rdm_net_forward_bf16)."""
+    from md_rdm_amd import _lib
+    L, st, P = _lib.lib(), _lib.stream(), _lib.ptr
+    M = B * H * W
+    Y = torch.relu(torch.from_numpy(U(f"c3n.y{H}", (B, H, W, Cc), -2.0, 2.0)).to(dev)).bfloat16()
+    w = torch.from_numpy(U(f"c3n.w{Cc}", (48, Cc, 3, 3), -0.05, 0.05)).to(dev)
+    wp = w.permute(2, 3, 0, 1).reshape(9, 48, Cc).contiguous().bfloat16()
+    want = F.conv2d(Y.float().permute(0, 3, 1, 2), w.bfloat16().float(), padding=1).permute(0, 2, 3, 1).reshape(M, 48)
+    wsb = int(L.rdm_conv3x3_bf16_workspace_bytes(Cc, B, H, W))
+    for ws_bytes in (0, wsb):
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+        out = torch.full((M, 48), float("nan"), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.rdm_conv3x3_bf16(P(Y), Cc, Cc, None, None, P(wp), P(out), 48, B, H, W, P(ws) if ws_bytes else None, ws_bytes, st))
+        err = (out.float() - want).abs().max().item()
+        assert err <= 6e-3 * want.abs().max().item(), (ws_bytes, err, want.abs().max().item())
