@@ -164,7 +164,8 @@ int rdm_unpack_conv_weight(const float* w_packed, float* w_oihw, int32_t out_c, 
 int rdm_gemm_bf16(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* bias,
                   void* out, int32_t ldc, int32_t m, int32_t n, int32_t out_f32, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 /* rdm_gemm_bf16 with the CONSUMER's eval-mode BatchNorm + ReLU in the epilogue: out = bf16(relu(acc * out_scale[n] + out_shift[n])) - the
- * dense layer's 1x1 in rdm_net_forward_bf16 (the 3x3 behind it then reads an already activated tensor: rdm_conv3x3_act_bf16). */
+ * dense layer's 1x1 in rdm_net_forward_bf16 (the 3x3 behind it then reads an already activated tensor: rdm_conv3x3_act_bf16).
+ * Many rows x many outputs x K <= 352 (dense_e2) run a persistent panel kernel (activations in registers, weight tiles by LDS-DMA). */
 int rdm_gemm_bf16_act(const void* x, int32_t ldx, int32_t k, const float* scale, const float* shift, const void* w, int32_t ldw, const float* out_scale,
                       const float* out_shift, void* out, int32_t ldc, int32_t m, int32_t n, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 size_t rdm_conv3x3_bf16_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w);

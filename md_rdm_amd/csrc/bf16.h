@@ -11,7 +11,8 @@ struct GemmBf16Args {        // out[m][n] = bias[n] + sum_k f(X[m][k]) * W[n][k]
   const float* bias;                       // optional f32[N]
   const float* oscale; const float* oshift; // optional f32[N]: out = relu(out*oscale[n] + oshift[n]) before the bf16 rounding (the CONSUMER's eval-mode BatchNorm + ReLU)
   float* partial; size_t partial_floats;   // optional f32 scratch for a K-split ([split][M][N] partial sums + one tiny reduction launch)
-  unsigned x_bytes, w_bytes, p_bytes;      // set by the launcher (buffer descriptors)
+  unsigned x_bytes, w_bytes, p_bytes, o_bytes;   // set by the launcher (buffer descriptors)
+  int abl;                                 // development builds: ablation bits (0 in the shipped build)
 };
 
 struct Conv3Bf16Args {       // out[m][n] = sum_{tap,c} relu(Y[pix(m,tap)][c]*scale[c]+shift[c]) * Wt[tap][n][c], zero padding, n < 48

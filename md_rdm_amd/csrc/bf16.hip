@@ -230,6 +230,205 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args p) {
   }
 }
 
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes at (voff + soff) land at lds_dst + 16*l (lds_dst wave-uniform: it goes to M0)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned char* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Short-K 1x1 with many pixels and many outputs (dense_e2: M = 34 656, N = 2752, K = 96 .. 336): persistent PANEL GEMM.
+// The tiled kernel above pays a workgroup's fixed costs (launch, address set-up, first-load latency, drain) 7859 times per layer for
+// 1.5 - 5 K-steps of work each, and every one of the 29 column tiles of a row panel re-loads AND re-normalises the same activations.
+// Here one persistent workgroup of 8 waves per CU walks a contiguous range of (256-row panel, 96-column tile) items, panel-major:
+//   * a wave owns 32 rows x 96 columns; its rows' activations live in REGISTERS as MFMA B fragments ([m-tile 2][32-deep k group
+//     <= 12] x 16 B per lane), loaded and BN-ReLU'd ONCE per panel (~29 items);
+//   * the item's weight tile ([K/64 steps][96 n][64 k] bf16, <= 72 KiB) comes by LDS-DMA, double-buffered by ITEM: the tile of item
+//     i+1 is requested right after the barrier that opens item i, so ONE barrier per item orders everything (the loads of item i have
+//     landed, every wave is past item i-1);  the consumer's BatchNorm coefficients of the 96 columns ride along as one more piece each;
+//   * the epilogue issues a FIXED number of stores (masked lanes store out of range), so the counted vmcnt wait stays exact:
+//     behind an item's DMA pieces a wave has issued 12 stores - nothing else;
+// LDS image of a K-step: [96 rows][128 B], 16-byte chunks XOR-swizzled (chunk ^ ((row >> 1) & 7)) on the DMA's source side.
+// (First version: 128-row panels, 4 consumer + 4 loader waves, an 8-stage ring with a barrier per K-step: 131 us at K = 240 where the
+// tiled kernel takes 150 - the weight stream alone, 377 MB through L2 -> LDS per launch, took 70 us.  256-row panels halve it.)
+// ---------------------------------------------------------------------------------------------
+constexpr int PANEL_STEP = 96 * 128, PANEL_EPI = 2048;
+
+template <int NKK>            // 32-deep K half-steps per item: 32 (NKK - 1) < K <= 32 NKK (compile-time: the multiply loop is one straight-line block)
+__global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p) {
+  constexpr int NKS = (NKK + 1) / 2;      // 64-deep K-steps (DMA granularity)
+  constexpr int BM = 256, BN = 96, NPIECE = NKS * 12, PW = (NPIECE + 7) / 8, BUF = NKS * PANEL_STEP;     // LDS: 2 weight buffers, then 4 coefficient slots
+  constexpr int NST = 12;                                             // store instructions per item and wave
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
+  const int ntn = (p.N + BN - 1) / BN, npan = (p.M + BM - 1) / BM;
+  const long items = (long)npan * ntn;
+  const int it0 = (int)((long)blockIdx.x * items / gridDim.x), it1 = (int)((long)(blockIdx.x + 1) * items / gridDim.x);
+  if (it0 == it1) return;
+  const __amdgpu_buffer_rsrc_t srdO = srd(p.out, p.o_bytes);
+  const __amdgpu_buffer_rsrc_t srdX = srd(p.X, p.x_bytes), srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
+  const __amdgpu_buffer_rsrc_t srdE = srd(wave == 0 ? p.oscale : p.oshift, (unsigned)(p.N * 4));
+  const bool bnrelu = p.scale != nullptr, oact = p.oscale != nullptr;
+
+  // DMA pieces of this wave: piece q = wave + 8*j of the item's NKS*12 (step = q / 12, 8 rows x 128 B each); the last column tile is ragged
+  const __amdgpu_buffer_rsrc_t srdW = srd(p.W, p.w_bytes);
+  unsigned voff[PW], lastmask = 0;                                    // bit j: piece j's row exists in the (ragged) last column tile
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int q = wave + 8 * j, ks = q / 12, r = (q - ks * 12) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    voff[j] = q < NPIECE ? (unsigned)r * (unsigned)(p.ldw * 2) + (unsigned)(ks * 128 + c * 16) : OOB;
+    if ((ntn - 1) * BN + r < p.N) lastmask |= 1u << j;
+  }
+  // (a pre-tiled weight image - every piece 1 KiB contiguous instead of 8 row segments - was tried: 86.5 vs 89.3 us, not worth a second copy)
+  const unsigned evoff = lane < 24 ? (unsigned)(lane * 16) : OOB;     // 96 floats of the column tile's scale (wave 0) / shift (wave 1)
+  auto request = [&](int item) {                                      // the weight tile (+ epilogue coefficients) of `item` -> buffer item & 1
+    const int t = item % ntn;
+    unsigned char* const dst = smem + (item & 1) * BUF;
+    const unsigned so = (unsigned)(t * BN) * (unsigned)(p.ldw * 2);
+    const bool last = t == ntn - 1;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      if (wave + 8 * j < NPIECE) dma16(srdW, (!last || ((lastmask >> j) & 1)) ? voff[j] : OOB, so, dst + (wave + 8 * j) * 1024);
+    if (wave < 2) dma16(srdE, (oact && !(last && (ntn - 1) * BN + (int)(lane * 4) >= p.N)) ? evoff : OOB, (unsigned)(t * BN * 4), smem + 2 * BUF + (item & 3) * PANEL_EPI + wave * 1024);
+  };
+
+  bf16x8 xr[2][NKK];
+  f32x4 acc[2][6];
+  const unsigned sw = (unsigned)((l16 >> 1) & 7);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto mma = [&](int item) {                                            // acc = the item's 32 x 96 products
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* const wrd = smem + (item & 1) * BUF + l16 * 128;   // weight fragment of column tile j, k-group kc: + j*2048 + ((kc ^ sw) << 4)
+    bf16x8 wf[2][6];                                                    // fragments of half-step kk+1 are read while kk multiplies (scheduler pinned)
+    auto frags = [&](int set, int kk) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(wrd + (kk >> 1) * PANEL_STEP + j * 2048 + ((((unsigned)((kk & 1) * 4 + g)) ^ sw) << 4));
+    };
+#ifdef RDM_DEV_VARIANTS
+    if (p.abl & 4) return;
+#endif
+    constexpr bool DB = true;                                            // (long K: the activations take the registers of the second fragment set)
+    frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      if (DB) { if (kk + 1 < NKK) frags((kk + 1) & 1, kk + 1); __builtin_amdgcn_sched_barrier(0); }
+      else if (kk > 0) frags(0, kk);
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[DB ? (kk & 1) : 0][j], xr[i][kk], acc[i][j], 0, 0, 0);
+      if (DB) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // epilogue: D[row = channel 4g+r of the n-tile][col = pixel l16 of the m-tile]; ALWAYS 12 store instructions per wave .
+  // The kernel is bound by vector-instruction ISSUE (in-kernel stamps: matrix-pipe time + VALU + DMA issue of a SIMD's two waves add
+  // up), so the epilogue is kept short: packed f32 FMAs, ReLU as a packed signed-16-bit max on the bf16 pairs (a negative bf16 is a
+  // negative int16), the column offset in the store's scalar offset, one out-of-range select per row instead of one per store.
+  // (Tried without effect on the 88 us of the K = 240 layer: the second wave of each SIMD running its epilogue one item late; a per-wave
+  // LDS transpose to 16-byte stores of 192 contiguous bytes per row; a pre-tiled weight image with 1-KiB contiguous DMA pieces.)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short i16x2 __attribute__((ext_vector_type(2)));
+  auto epilogue = [&](int m0, int n0, int slot) {
+    const float* const ep = reinterpret_cast<const float*>(smem + 2 * BUF + (slot & 3) * PANEL_EPI);
+    const bool ragged = n0 + BN > p.N;                                  // (uniform) the last column tile: per-lane column checks
+    unsigned rowoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + i * 16 + l16;
+      bool ok = slot >= 0 && m < p.M;
+#ifdef RDM_DEV_VARIANTS
+      if (p.abl & 1) ok = false;
+#endif
+      rowoff[i] = ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(n0 + g * 4)) * 2u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 os = f32x4{1.f, 1.f, 1.f, 1.f}, oh = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (oact && slot >= 0) { os = *reinterpret_cast<const f32x4*>(ep + j * 16 + g * 4); oh = *reinterpret_cast<const f32x4*>(ep + 256 + j * 16 + g * 4); }
+      const f32x2 os01 = {os[0], os[1]}, os23 = {os[2], os[3]}, oh01 = {oh[0], oh[1]}, oh23 = {oh[2], oh[3]};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x2 a01 = {acc[i][j][0], acc[i][j][1]}, a23 = {acc[i][j][2], acc[i][j][3]};
+        if (oact) { a01 = __builtin_elementwise_fma(a01, os01, oh01); a23 = __builtin_elementwise_fma(a23, os23, oh23); }
+        unsigned p01 = pack2(a01[0], a01[1]), p23 = pack2(a23[0], a23[1]);
+        if (oact) {
+          p01 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, p01), i16x2{0, 0}));
+          p23 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, p23), i16x2{0, 0}));
+        }
+        const u32x2 pk = {p01, p23};
+        unsigned off = rowoff[i];
+        if (ragged && n0 + j * 16 + g * 4 >= p.N) off = OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(pk, srdO, (int)off, j * 32, 0);   // (the column tile offset rides in soffset: it is outside the range check)
+      }
+    }
+  };
+  int cur_pan = -1;
+  request(it0);
+  for (int item = it0; item < it1; ++item) {
+    const int pan = item / ntn, t = item - pan * ntn;
+    const int m0 = pan * BM + wave * 32, n0 = t * BN;
+    if (pan != cur_pan) {                                               // a new row panel: its activations, normalised once, as B fragments
+      cur_pan = pan;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int k0 = kk * 32 + g * 8;
+        const bool kok = k0 < p.K;                                      // K is a multiple of 8
+        float4 sa, sb, ta, tb;
+        if (bnrelu) {
+          const unsigned po = kok ? (unsigned)(k0 * 4) : OOB;
+          sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
+          ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int m = m0 + i * 16 + l16;
+          uint4 v = bld(srdX, (kok && m < p.M) ? (unsigned)m * (unsigned)(p.ldx * 2) + (unsigned)(k0 * 2) : OOB);
+          if (bnrelu) v = bnrelu8(v, sa, sb, ta, tb);
+          if (!kok) v = make_uint4(0, 0, 0, 0);                         // columns past K multiply (finite) weights of the next row: force exact zeros
+          xr[i][kk] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the counted wait below assumes nothing but pieces and stores in flight)
+    }
+    // this item's pieces have landed: behind them this wave issued exactly 12 stores (of an earlier item, or the dummies; none before the first)
+#ifdef RDM_DEV_VARIANTS
+    const long t0 = __builtin_readcyclecounter();
+#endif
+    if (item == it0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+#ifdef RDM_DEV_VARIANTS
+    const long t1 = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_barrier();                                       // ... everybody's have; every wave is past the other buffer (item - 1)
+    asm volatile("" ::: "memory");
+#ifdef RDM_DEV_VARIANTS
+    const long t2 = __builtin_readcyclecounter();
+#endif
+    if (item + 1 < it1) request(item + 1);
+#ifdef RDM_DEV_VARIANTS
+    const long t3 = __builtin_readcyclecounter();
+    long t4;
+#endif
+    mma(item);
+#ifdef RDM_DEV_VARIANTS
+    asm volatile("s_nop 0" ::: "memory");
+    t4 = __builtin_readcyclecounter();
+#endif
+    epilogue(m0, n0, item);
+#ifdef RDM_DEV_VARIANTS
+    if ((p.abl & 8) && p.partial && blockIdx.x == 3 && lane == 0) {
+      const long t5 = __builtin_readcyclecounter();
+      float* d = p.partial + wave * 8;
+      d[0] += (float)(t1 - t0); d[1] += (float)(t2 - t1); d[2] += (float)(t3 - t2); d[3] += (float)(t4 - t3); d[4] += (float)(t5 - t4); d[5] += 1.f;
+    }
+#endif
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 / 48 outputs on a zero-PADDED LDS image.  A block owns BM = MT*64 consecutive output pixels (linear
 // NHWC index).  Its input neighbourhood is staged as a 2-D image of padded rows: every image row gets a zero column on both
@@ -410,12 +609,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3Bf16Args p) {
 //     ascending split order - no second launch, no atomics on data, same bits every run.
 // C must be a multiple of 32 (the network pads its bottleneck widths; pad channels are zero on both operands).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned char* lds_dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
-#endif
-}
-
 constexpr int ACT_IMG_BYTES = 52 * 1024, ACT_W_BYTES = 27 * 1024, ACT_MAX_SLOTS = ACT_IMG_BYTES / 64;     // 832 padded pixels
 constexpr int ACT_LDS_BYTES = 2 * (ACT_IMG_BYTES + ACT_W_BYTES);
 
@@ -839,7 +1032,29 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   } while (0)
   // (measured at M = 2280: 64x48 / 64x96 / 128x48 / 128x96 tiles and 2 vs 4 register stages all land at 21-26 us - the kernel is
   // bound by instruction issue, ~140 non-MFMA instructions per 64-deep step of which the BN-ReLU staging transform is the largest part)
-  if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64, 2);
+  // many pixels x many outputs x short K (dense_e2): the persistent panel kernel
+#ifdef RDM_DEV_VARIANTS
+  a.abl = g_variant >= 200 && g_variant < 216 ? g_variant - 200 : 0;
+#endif
+  const bool panel = !out_f32 && !a.bias && split == 1 && a.K <= 352 && a.M >= 8192 && a.N >= 1024 && (long)cdiv(a.M, 256) * cdiv(a.N, 96) >= 1024;
+  if (panel) {
+    static int n_cu = 0;
+    if (!n_cu) { hipDeviceProp_t pr; int dev = 0; RDM_HIP_OK(hipGetDevice(&dev)); RDM_HIP_OK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
+    const int nkk = cdiv(a.K, 32), nks = (nkk + 1) / 2, lds = 2 * nks * PANEL_STEP + 4 * PANEL_EPI;
+    const long ob = ((long)(a.M - 1) * a.ldc + a.N) * 2;
+    if (ob >= 0xFFFFFFFFL) { set_error("gemm_bf16: output extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
+    a.o_bytes = (unsigned)ob;
+    dim3 grid((unsigned)n_cu);
+#define RDM_GP(NKK_)                                                                                                                      \
+  case NKK_: {                                                                                                                             \
+    static bool attr_set = false;                                                                                                          \
+    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_bf16_kernel<NKK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((NKK_ + 1) / 2) * PANEL_STEP + 4 * PANEL_EPI)); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_panel_bf16_kernel<NKK_>), grid, dim3(512), lds, s, a);                                                        \
+  } break
+    switch (nkk) { RDM_GP(1); RDM_GP(2); RDM_GP(3); RDM_GP(4); RDM_GP(5); RDM_GP(6); RDM_GP(7); RDM_GP(8); RDM_GP(9); RDM_GP(10); RDM_GP(11); default: break; }
+#undef RDM_GP
+    RDM_CENSUS("gemm_panel_bf16_kernel/nkk%d", cdiv(a.K, 32));
+  } else if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64, 2);
   else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1, 64, 2);
   else if (a.M > 1024) RDM_G(2, 3, 2, 2, 64, 2);                         // 64 x 96
   else RDM_G(1, 3, 2, 2, 64, 2);                                         // 32 x 96

@@ -32,6 +32,9 @@ for v in variants:
                                                            P(wsg) if M <= 1024 else None, wsg.numel() if M <= 1024 else 0, st)))
             fl = 2.0 * M * N * K; by = 2.0 * (M * K + N * K + M * N)
             print(f"v{v} gemm {name:9s} M={M:6d} K={K:5d} N={N:5d} prologue={pro}: {us:8.1f} us  {fl/us/1e6:7.1f} TF  {by/us/1e3:7.1f} GB/s", flush=True)
+        osc = torch.rand(N, device=dev) + 0.5; osh = torch.rand(N, device=dev) - 0.5
+        us = timeit(lambda: _lib.check(L.rdm_gemm_bf16_act(P(X), ldx, K, P(sc), P(sh), P(W), K, P(osc), P(osh), P(out), N, M, N, None, 0, st)))
+        print(f"v{v} gemm_act {name:9s} M={M:6d} K={K:5d} N={N:5d}: {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
     for name, b, H, W_, Cc in (shapes_c if only in ("", "conv3") else []):
         M = b * H * W_
         Y = torch.randn(M, Cc, device=dev).bfloat16(); Wp = (torch.randn(9, 48, Cc, device=dev) * 0.02).bfloat16()
