@@ -317,7 +317,7 @@ def bench_fwd_bf16(args):
         h = model._plan(B, H, W)[0]
         PEAK_MFMA, PEAK_HBM = 2500.0, 8000.0                     # dense bf16 MFMA TFLOP/s, HBM3E GB/s (MI355X_MICROARCH.md)
         per_kernel = []
-        for kind in (7, 8):
+        for kind in (7, 8, 11, 12):
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             kby = L.rdm_profile_kind_bytes(kind)

@@ -48,10 +48,10 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..10 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
- * 7-8 the bf16 forward kernels, 9-10 the Winograd f32 forward / weight-gradient kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..12 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
+ * 7-8 and 11-12 the bf16 forward kernels, 9-10 the Winograd f32 forward / weight-gradient kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
-/* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for kinds 0-6) */
+/* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for the f32 kinds) */
 double rdm_profile_kind_bytes(int32_t kind);
 /* development switch for in-process A/B timing of the measured alternatives DESIGN.md 4.1 cites (0 = shipped):
  * 7 generic instead of halo 3x3, 8 no forward pipelining, 9 generic instead of row wgrad, 11 hardware block order,

@@ -1011,7 +1011,6 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   const long xb = ((long)(a.M - 1) * a.ldx + a.K) * 2, wb = ((long)(a.N - 1) * a.ldw + a.K) * 2;
   if (xb >= 0xFFFFFFFFL || wb >= 0xFFFFFFFFL) { set_error("gemm_bf16: operand extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.p_bytes = (unsigned)(a.K * 4);
-  void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, 7, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (double)a.M * a.N * (out_f32 ? 4 : 2));
   // tiles: 128 x 96 on big grids whose N is (nearly) a multiple of 96, 128 x 48 else; few pixels: 64 x 48 / 32 x 96 (more workgroups)
   const long t96 = (long)cdiv(a.M, 128) * cdiv(a.N, 96);
   const bool n96 = (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N;
@@ -1036,7 +1035,9 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
 #ifdef RDM_DEV_VARIANTS
   a.abl = g_variant >= 200 && g_variant < 216 ? g_variant - 200 : 0;
 #endif
+  // (at dense_e3's 525 items - two per workgroup - it only ties the tiled kernel: 37.3 vs 37.0 us at K = 336)
   const bool panel = !out_f32 && !a.bias && split == 1 && a.K <= 352 && a.M >= 8192 && a.N >= 1024 && (long)cdiv(a.M, 256) * cdiv(a.N, 96) >= 1024;
+  void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, panel ? 11 : 7, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (double)a.M * a.N * (out_f32 ? 4 : 2));
   if (panel) {
     static int n_cu = 0;
     if (!n_cu) { hipDeviceProp_t pr; int dev = 0; RDM_HIP_OK(hipGetDevice(&dev)); RDM_HIP_OK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
@@ -1208,7 +1209,7 @@ int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
 #ifdef RDM_DEV_VARIANTS
   a.abl = g_variant >= 100 && g_variant < 116 ? g_variant - 100 : 0;
 #endif
-  void* tk = profile_begin(s, 2.0 * M * 48.0 * a.C * 9.0, 8, 2.0 * ((double)M * a.C + 9.0 * 48 * a.C + (double)M * 48));
+  void* tk = profile_begin(s, 2.0 * M * 48.0 * a.C * 9.0, 12, 2.0 * ((double)M * a.C + 9.0 * 48 * a.C + (double)M * 48));
   dim3 grid((unsigned)(a.B * pl.tpi), (unsigned)pl.split);
 #define RDM_C3A(NC_)                                                                                                                      \
   case NC_: {                                                                                                                              \

@@ -985,13 +985,14 @@ struct ProfScope {
   ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind, bytes}); } }
 };
 // per-kernel breakdown of the last profile_read()
-constexpr int PROF_KINDS = 11;
+constexpr int PROF_KINDS = 13;
 const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
     "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel",
     "gemm_bf16_kernel (1x1 forward, bf16 MFMA)", "conv3x3_bf16_kernel (3x3 forward, bf16 MFMA)",
     "conv3x3_wino_fwd_kernel (Winograd F(2x2,3x3) forward; FLOPs = the direct convolution's)",
-    "conv3x3_wino_wgrad_kernel (Winograd F(3x3,2x2) weight gradient; FLOPs = the direct convolution's)"};
+    "conv3x3_wino_wgrad_kernel (Winograd F(3x3,2x2) weight gradient; FLOPs = the direct convolution's)",
+    "gemm_panel_bf16_kernel (short-K 1x1 forward, persistent panels, bf16 MFMA)", "conv3x3_act_bf16_kernel (3x3 forward on an activated input, LDS-DMA, bf16 MFMA)"};
 double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS], g_kind_bytes[PROF_KINDS];
 int g_kind_n[PROF_KINDS];
 }  // namespace

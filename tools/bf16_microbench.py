@@ -7,7 +7,7 @@ from md_rdm_amd import _lib
 L = _lib.lib(); P = _lib.ptr; dev = torch.device("cuda:0")
 variants = [int(v) for v in sys.argv[1:]] or [0]
 B = 8
-shapes_g = [("e2.conv1", B*57*76, 240, 2736, 384), ("e3.conv1", B*29*38, 456, 1392, 768), ("e4.conv1", B*15*19, 1224, 720, 2112), ("d1.conv1", B*8*10, 1632, 384, 2208),
+shapes_g = [("e2.conv1", B*57*76, 240, 2736, 384), ("e3.k336", B*29*38, 336, 1408, 768), ("e3.k192", B*29*38, 192, 1408, 768), ("e3.conv1", B*29*38, 456, 1392, 768), ("e4.conv1", B*15*19, 1224, 720, 2112), ("d1.conv1", B*8*10, 1632, 384, 2208),
             ("stem", B*114*152, 160, 96, 160), ("trans_e2", B*29*38, 384, 192, 384)]
 shapes_c = [("e2.conv2", B, 57, 76, 2736), ("e3.conv2", B, 29, 38, 1392), ("e4.conv2", B, 15, 19, 720), ("d1.conv2", B, 8, 10, 384)]
 def timeit(fn, n=int(os.environ.get('REPS', '30'))):
