@@ -3,7 +3,7 @@ import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 seen={}
 for r in rows:
-    if any(k in r['Kernel_Name'] for k in ('conv_','conv3x3','gemm_bf16')):
+    if any(k in r['Kernel_Name'] for k in ('conv_','conv3x3','gemm_bf16','gemm_panel')):
         d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
         seen.setdefault((r['Dispatch_Id'],r['Kernel_Name'][10:58],r['Grid_Size'],r['VGPR_Count'],r['LDS_Block_Size']),{'dur':d})[r['Counter_Name']]=float(r['Counter_Value'])
 last={}
