@@ -179,7 +179,7 @@ int rdm_conv3x3_bf16(const void* y, int32_t ldy, int32_t channels, const float* 
  *                              behind the real channel count must be finite: their weights are zero), out (B*H*W, ldc) bf16.
  *                              workspace (optional, 256-byte aligned, rdm_conv3x3_act_bf16_workspace_bytes): tile counters + f32 partial
  *                              sums of a K-split; the last workgroup of a tile adds them in a fixed order inside the same launch (deterministic).
- *                              RDM_ERR_UNSUPPORTED (nothing launched) when a tile's rows do not fit the 160 KB LDS (rows wider than ~250 pixels). */
+ *                              Rows too wide for whole-row tiles (above ~200 pixels) take 64-column rectangular tiles. */
 size_t rdm_conv3x3_act_bf16_weight_bytes(int32_t channels);
 int rdm_conv3x3_act_bf16_pack(const float* w_oihw, int32_t channels, void* w_image, rdm_stream_t stream);
 size_t rdm_conv3x3_act_bf16_workspace_bytes(int32_t channels_padded, int32_t batch, int32_t h, int32_t w);

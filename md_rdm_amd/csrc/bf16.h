@@ -34,7 +34,7 @@ struct Conv3ActArgs {        // out[m][n] = sum_{tap,c} Y[pix(m,tap)][c] * w[n][
   int B, H, W;
   float* partial; size_t partial_floats;   // optional f32 scratch for the K-split ([tile][split][BM][48])
   unsigned* counters; int n_counters;      // one per tile, ZERO on entry, left zero (needed when partial != NULL)
-  int split, slots, tiles_per_img;         // set by the launcher
+  int split, slots, tiles_per_img, rect;   // set by the launcher (rect: 64-column rectangular tiles for rows too wide for whole-row tiles)
   unsigned y_bytes, w_bytes;
   int abl;                                 // development builds: ablation bits (0 in the shipped build)
 };

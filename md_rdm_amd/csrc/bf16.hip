@@ -619,11 +619,23 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
   constexpr int WP = (WPIECES + NC - 1) / NC;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;   // (uniform: LDS-DMA targets go to M0)
-  const int W = p.W, H = p.H, Wp = W + 2, HW = H * W;
+  const int W = p.W, H = p.H, HW = H * W;
   const int tile = blockIdx.x, b = tile / p.tiles_per_img, t = tile - b * p.tiles_per_img;
-  const int ml0 = t * BM, mlN = min(HW, ml0 + BM);                    // this tile's pixels inside image b
-  const int y0 = ml0 / W, y1 = (mlN - 1) / W;
-  const int nslots = (y1 - y0 + 3) * Wp, npieces = (nslots + 15) >> 4;   // padded rows y0-1 .. y1+1; <= ACT_MAX_SLOTS / 16 (launcher)
+  // Tile geometry.  Narrow rows (p.rect == 0): BM consecutive pixels of image b in row-major order - whole rows, ragged at both ends.
+  // Wide rows (the padded rows of such a tile would not fit the LDS image, e.g. 304 pixels at 352x1216): a RECTANGLE of BM / 64 rows x 64
+  // columns.  Either way: local pixel ml -> image (y, x); LDS image = rows y0-1 .. , columns x0-1 .. x0+Wt, Wp = Wt + 2 slots per row.
+  constexpr int RTW = 64;
+  const bool rect = p.rect != 0;
+  const int tiles_x = rect ? (W + RTW - 1) / RTW : 1;
+  const int ml0 = rect ? 0 : t * BM, mlN = rect ? BM : min(HW, ml0 + BM);
+  const int y0 = rect ? (t / tiles_x) * (BM / RTW) : ml0 / W, x0 = rect ? (t % tiles_x) * RTW : 0;
+  const int Wt = rect ? RTW : W, Wp = Wt + 2;
+  const int nrows = rect ? BM / RTW + 2 : (mlN - 1) / W - y0 + 3;
+  const int nslots = nrows * Wp, npieces = (nslots + 15) >> 4;        // <= ACT_MAX_SLOTS / 16 (launcher)
+  auto pixel = [&](int ml, int& y, int& x) -> bool {                  // image coordinates of local pixel ml; false: not an output of this tile
+    if (rect) { y = y0 + (ml >> 6); x = x0 + (ml & (RTW - 1)); return y < H && x < W; }
+    const int gl = ml0 + ml; y = gl / W; x = gl - y * W; return gl < mlN;
+  };
   const int ncs_all = p.C >> 5, split = (int)gridDim.y;
   const int per = (ncs_all + split - 1) / split;
   const int cs0 = blockIdx.y * per, cs1 = min(ncs_all, cs0 + per);   // the launcher leaves no split empty
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
       const int sl = (lw + i * NC) * 16 + (lane >> 2), c = (lane & 3) ^ (((sl >> 2) & 1) << 1);
-      const int prow = sl / Wp, x = sl - prow * Wp - 1, y = y0 - 1 + prow;
+      const int prow = sl / Wp, x = x0 + sl - prow * Wp - 1, y = y0 - 1 + prow;
       const bool ok = sl < nslots && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
       voff[i] = ok ? (unsigned)((b * H + y) * W + x) * (unsigned)(p.ldy * 2) + (unsigned)(c * 16) : OOB;
     }
@@ -678,9 +690,9 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
     unsigned fpk[MT][5];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int ml = min(ml0 + wave * 128 + i * 16 + l16, mlN - 1);   // rows past the tile are never stored: any in-range address will do
-      const int y = ml / W, x = ml - y * W;
-      const int sc = (y - y0 + 1) * Wp + x + 1;
+      int y, x;
+      pixel(min(wave * 128 + i * 16 + l16, mlN - ml0 - 1), y, x);     // rows past the tile are never stored: any in-range address will do
+      const int sc = (y - y0 + 1) * Wp + (x - x0) + 1;
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
         const int sl = sc + (tp / 3 - 1) * Wp + (tp % 3 - 1);
@@ -688,7 +700,8 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
         if (tp & 1) fpk[i][tp >> 1] |= a16 << 16; else fpk[i][tp >> 1] = a16;
       }
     }
-    const bool active = ml0 + wave * 128 < mlN;                       // ragged last tile of an image: idle consumers only synchronise
+    int ya, xa;
+    const bool active = pixel(wave * 128, ya, xa);                    // ragged last tile of an image: idle consumers only synchronise
     // one slab from the stage at compile-time LDS offsets: 18 steps (tap, half of the 8 m-tiles) of 12 MFMAs; the fragments of step
     // k+1 are read while step k multiplies (two register sets; the scheduler is pinned, it would otherwise fold the sets and wait on every read)
     auto slab = [&](auto stc) {
@@ -748,8 +761,9 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
     }
   }
 
-  const long pix0 = (long)b * HW + ml0;
-  const bool store = !loader && ml0 + wave * 128 < mlN;
+  const long pixb = (long)b * HW;
+  int ys, xs;
+  const bool store = !loader && pixel(wave * 128, ys, xs);
   if (split == 1) {
     if (!store) return;
 #pragma unroll
@@ -757,9 +771,9 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
       const int n = j * 16 + g * 4;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int r = wave * 128 + i * 16 + l16;
-        if (ml0 + r < mlN)
-          *reinterpret_cast<uint2*>(p.out + (pix0 + r) * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
+        int y, x;
+        if (pixel(wave * 128 + i * 16 + l16, y, x))
+          *reinterpret_cast<uint2*>(p.out + (pixb + (long)y * W + x) * p.ldc + n) = make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
       }
     }
     return;
@@ -794,7 +808,6 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
   if (!*flag) return;
   // every thread owns 12 float4 of the tile (BM*12 / NTHR); a slab element comes from the memory side (~1.5 us): all loads of 6
   // elements x 6 slabs are issued before the first add - 2 round trips for a split <= 6 instead of 12 x split
-  const int nrow = mlN - ml0;
   constexpr int G = 6, ZB = 5;
 #pragma unroll
   for (int k0 = 0; k0 < 12; k0 += G) {
@@ -803,7 +816,8 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       const int idx = tid + (k0 + k) * NTHR, r = idx / 12;
-      off[k] = r < nrow ? (unsigned)idx * 16u : OOB;                  // idx*16 = (r*48 + q4*4)*4
+      int y, x;
+      off[k] = pixel(r, y, x) ? (unsigned)idx * 16u : OOB;            // idx*16 = (r*48 + q4*4)*4
       a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int z0 = 0; z0 < split; z0 += ZB) {
@@ -821,7 +835,8 @@ __global__ __launch_bounds__(NC * 128, 2) void conv3x3_act_bf16_kernel(Conv3ActA
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       const int idx = tid + (k0 + k) * NTHR, r = idx / 12, q4 = idx - r * 12;
-      if (r < nrow) *reinterpret_cast<uint2*>(p.out + (pix0 + r) * p.ldc + q4 * 4) = make_uint2(pack2(a[k][0], a[k][1]), pack2(a[k][2], a[k][3]));
+      int y, x;
+      if (pixel(r, y, x)) *reinterpret_cast<uint2*>(p.out + (pixb + (long)y * W + x) * p.ldc + q4 * 4) = make_uint2(pack2(a[k][0], a[k][1]), pack2(a[k][2], a[k][3]));
     }
   }
 }
@@ -1142,7 +1157,7 @@ int launch_conv3x3_bf16(const Conv3Bf16Args& a_in, hipStream_t s) {
 
 // ---- conv3x3_act_bf16_kernel: tile / split choice ----
 namespace {
-struct Conv3ActPlan { int nc = 0, split = 1, tpi = 0; double cost = 0; };
+struct Conv3ActPlan { int nc = 0, split = 1, tpi = 0, rect = 0; double cost = 0; };
 // max zero-padded LDS slots over the tiles of one image
 int act_slots(int H, int W, int bm) {
   const int HW = H * W, tpi = cdiv(HW, bm);
@@ -1153,9 +1168,11 @@ int act_slots(int H, int W, int bm) {
 bool plan_conv3_act(int C, int B, int H, int W, size_t partial_floats, int n_counters, Conv3ActPlan& best) {
   const int HW = H * W, slabs = C / 32;
   best = Conv3ActPlan{};
-  for (int nc = 1; nc <= 4; ++nc) {
-    const int bm = nc * 128, tpi = cdiv(HW, bm);
-    if (act_slots(H, W, bm) > ACT_MAX_SLOTS) continue;
+  for (int pass = 0; pass < 2 && best.nc == 0; ++pass)                 // pass 1 (nothing fits as whole rows): 64-column rectangles
+  for (int nc = 1; nc <= 4; nc += pass ? nc : 1) {                     // (rectangles of 2, 4, 8 rows: nc 1, 2, 4)
+    const int bm = nc * 128;
+    const int tpi = pass ? cdiv(H, bm / 64) * cdiv(W, 64) : cdiv(HW, bm);
+    if (!pass && act_slots(H, W, bm) > ACT_MAX_SLOTS) continue;
     const long tiles = (long)B * tpi;
     for (int sp = 1; sp <= std::min(slabs, 32); ++sp) {
       const int per = cdiv(slabs, sp), spe = cdiv(slabs, per);
@@ -1165,7 +1182,7 @@ bool plan_conv3_act(int C, int B, int H, int W, size_t partial_floats, int n_cou
       // microseconds.  Per slab: 216 MFMAs per consumer (1.7) or, when few workgroups run, the DMA round trip (1.2); prologue +
       // epilogue 3; ordered combine: 2 memory round trips per 6 slabs
       const double cost = (double)rounds * (per * 1.8 + 3.0) + (spe > 1 ? 1.0 + 2 * cdiv(spe, 6) * 1.7 : 0.0);
-      if (best.nc == 0 || cost < best.cost * 0.98) { best.nc = nc; best.split = spe; best.tpi = tpi; best.cost = cost; }
+      if (best.nc == 0 || cost < best.cost * 0.98) { best.nc = nc; best.split = spe; best.tpi = tpi; best.rect = pass; best.cost = cost; }
     }
   }
   return best.nc != 0;
@@ -1205,7 +1222,7 @@ int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
     set_error("conv3x3_act_bf16: rows of %d pixels do not fit the LDS image", a.W);
     return RDM_ERR_UNSUPPORTED;
   }
-  a.split = pl.split; a.slots = ACT_MAX_SLOTS; a.tiles_per_img = pl.tpi;
+  a.split = pl.split; a.slots = ACT_MAX_SLOTS; a.tiles_per_img = pl.tpi; a.rect = pl.rect;
 #ifdef RDM_DEV_VARIANTS
   a.abl = g_variant >= 100 && g_variant < 116 ? g_variant - 100 : 0;
 #endif
@@ -1222,7 +1239,7 @@ int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
     default: set_error("conv3x3_act_bf16: bad plan"); return RDM_ERR_UNSUPPORTED;
   }
 #undef RDM_C3A
-  RDM_CENSUS("conv3x3_act_bf16_kernel/nc%d/%s", pl.nc, pl.split > 1 ? "splitK" : "direct");
+  RDM_CENSUS("conv3x3_act_bf16_kernel/nc%d/%s%s", pl.nc, pl.split > 1 ? "splitK" : "direct", pl.rect ? "/rect" : "");
   profile_end(tk, s);
   RDM_LAUNCH_OK();
   return 0;

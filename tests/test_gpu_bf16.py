@@ -81,6 +81,22 @@ def test_bf16_b8_228x304_vs_f32_path_and_sample_independence(dev):
     assert torch.equal(P, P_again) and torch.equal(dec, dec_again)
 
 
+def test_bf16_kitti_geometry_352x1216_vs_f32_path(dev):
+    """BASELINE configs[4]'s geometry on the bf16 path (what `--precision 16` validates on): dense_e2 has rows of 304 pixels, whose 3x3
+    takes the 64-column rectangular tiles of conv3x3_act_bf16_kernel."""
+    B, H, W = 2, 352, 1216
+    x, _ = filler.synthetic_batch(B, H, W, seed=77)
+    xg = torch.from_numpy(x).to(dev)
+    m = make_model(dev)
+    with torch.no_grad():
+        _, dec32, P32 = m(xg)
+        lg32 = m._native_forward(xg).cpu().numpy()
+        m.set_precision("bf16")
+        _, dec, P = m(xg)
+        lg = m._native_forward_bf16(xg).cpu().numpy()
+    head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, dec32.cpu().numpy(), P32.cpu().numpy(), lg32)
+
+
 def test_bf16_is_inference_only_and_tracks_weight_updates(dev):
     from md_rdm_amd import _lib
     m = make_model(dev).set_precision("bf16")
@@ -166,12 +182,13 @@ def test_conv3x3_bf16_operator(dev, B, H, W, Cc):
 
 
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 57, 76, 2736), (8, 29, 38, 1392), (3, 15, 19, 720), (2, 8, 10, 384), (1, 11, 38, 384), (1, 23, 90, 96),
-                                      (5, 9, 13, 64)])
+                                      (5, 9, 13, 64), (1, 23, 304, 96), (2, 41, 260, 64), (1, 88, 304, 480)])
 def test_conv3x3_act_bf16_operator(dev, op_census, B, H, W, Cc):
     """rdm_conv3x3_act_bf16 (input already activated, both operands by LDS-DMA, zero padding by out-of-range source offsets, K-split
     combined inside the launch by the tile's last workgroup) vs torch conv2d in f32 on the same bf16-rounded operands.  Channel counts
     48*odd are padded to a multiple of 32 (finite garbage behind the real channels: their weights are zero); the shapes take tiles of
-    2..8 waves, ragged last tiles of an image, rows that wrap inside a 16-pixel fragment, with and without the split."""
+    2..8 waves, ragged last tiles of an image, rows that wrap inside a 16-pixel fragment, with and without the split; rows of 260 / 304
+    pixels (the dense_e2 of a 352x1216 input) take the 64-column rectangular tiles."""
     from md_rdm_amd import _lib
     L, st, P = _lib.lib(), _lib.stream(), _lib.ptr
     M = B * H * W
@@ -203,6 +220,8 @@ def test_conv3x3_act_bf16_operator(dev, op_census, B, H, W, Cc):
     _lib.check(L.rdm_conv3x3_act_bf16(P(Y), ldy, Cp, P(wimg), C.c_void_p(out2.data_ptr() + 2 * 16), ldc, B, H, W, P(ws), wsb, st))
     assert torch.equal(out2[:, 16:64].view(torch.int16), outs[1].view(torch.int16))
     assert any(k.startswith("conv3x3_act_bf16_kernel/") for k in _lib.census())
+    if W > 250:
+        assert any(k.endswith("/rect") for k in _lib.census())
 
 
 @pytest.mark.parametrize("M,K,N,ld_pad", [(34656, 144, 2752, 48), (2280, 1056, 736, 96), (285, 2064, 736, 48), (80, 2160, 384, 48),
