@@ -254,6 +254,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
 // tiled kernel takes 150 - the weight stream alone, 377 MB through L2 -> LDS per launch, took 70 us.  256-row panels halve it.)
 // ---------------------------------------------------------------------------------------------
 constexpr int PANEL_STEP = 96 * 128, PANEL_EPI = 2048;
+#ifdef RDM_DEV_VARIANTS
+#define RDM_STAMP(v) const long v = __builtin_readcyclecounter()
+#else
+#define RDM_STAMP(v)
+#endif
 
 template <int NKK>            // 32-deep K half-steps per item: 32 (NKK - 1) < K <= 32 NKK (compile-time: the multiply loop is one straight-line block)
 __global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p) {
@@ -394,34 +399,22 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the counted wait below assumes nothing but pieces and stores in flight)
     }
-    // this item's pieces have landed: behind them this wave issued exactly 12 stores (of an earlier item, or the dummies; none before the first)
-#ifdef RDM_DEV_VARIANTS
-    const long t0 = __builtin_readcyclecounter();
-#endif
+    // this item's pieces have landed: behind them this wave issued exactly the previous item's 12 stores (nothing before the first item)
+    RDM_STAMP(t0);
     if (item == it0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-#ifdef RDM_DEV_VARIANTS
-    const long t1 = __builtin_readcyclecounter();
-#endif
+    RDM_STAMP(t1);
     __builtin_amdgcn_s_barrier();                                       // ... everybody's have; every wave is past the other buffer (item - 1)
     asm volatile("" ::: "memory");
-#ifdef RDM_DEV_VARIANTS
-    const long t2 = __builtin_readcyclecounter();
-#endif
+    RDM_STAMP(t2);
     if (item + 1 < it1) request(item + 1);
-#ifdef RDM_DEV_VARIANTS
-    const long t3 = __builtin_readcyclecounter();
-    long t4;
-#endif
+    RDM_STAMP(t3);
     mma(item);
-#ifdef RDM_DEV_VARIANTS
-    asm volatile("s_nop 0" ::: "memory");
-    t4 = __builtin_readcyclecounter();
-#endif
+    RDM_STAMP(t4);
     epilogue(m0, n0, item);
 #ifdef RDM_DEV_VARIANTS
-    if ((p.abl & 8) && p.partial && blockIdx.x == 3 && lane == 0) {
-      const long t5 = __builtin_readcyclecounter();
+    if ((p.abl & 8) && p.partial && blockIdx.x == 3 && lane == 0) {     // tools/panel_gemm_stamps.py: cycles per phase, per wave of one workgroup
+      RDM_STAMP(t5);
       float* d = p.partial + wave * 8;
       d[0] += (float)(t1 - t0); d[1] += (float)(t2 - t1); d[2] += (float)(t3 - t2); d[3] += (float)(t4 - t3); d[4] += (float)(t5 - t4); d[5] += 1.f;
     }
