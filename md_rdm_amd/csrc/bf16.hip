@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p)
   const int it0 = (int)((long)blockIdx.x * items / gridDim.x), it1 = (int)((long)(blockIdx.x + 1) * items / gridDim.x);
   if (it0 == it1) return;
   const __amdgpu_buffer_rsrc_t srdO = srd(p.out, p.o_bytes);
-  const __amdgpu_buffer_rsrc_t srdX = srd(p.X, p.x_bytes), srdS = srd(p.scale, p.p_bytes), srdT = srd(p.shift, p.p_bytes);
+  const __amdgpu_buffer_rsrc_t srdX = srd(p.X, p.x_bytes);
   const __amdgpu_buffer_rsrc_t srdE = srd(wave == 0 ? p.oscale : p.oshift, (unsigned)(p.N * 4));
   const bool bnrelu = p.scale != nullptr, oact = p.oscale != nullptr;
 
@@ -371,6 +371,11 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p)
       }
     }
   };
+  // the producer-side BatchNorm affine of the K input channels, once per workgroup: [scale NKK*32][shift NKK*32] floats behind the coefficient slots
+  float* const coef = reinterpret_cast<float*>(smem + 2 * BUF + 4 * PANEL_EPI);
+  if (bnrelu)
+    for (int c = tid; c < NKK * 32; c += 512) { coef[c] = c < p.K ? p.scale[c] : 0.f; coef[NKK * 32 + c] = c < p.K ? p.shift[c] : 0.f; }
+  __syncthreads();
   int cur_pan = -1;
   request(it0);
   for (int item = it0; item < it1; ++item) {
@@ -378,26 +383,32 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_bf16_kernel(GemmBf16Args p)
     const int m0 = pan * BM + wave * 32, n0 = t * BN;
     if (pan != cur_pan) {                                               // a new row panel: its activations, normalised once, as B fragments
       cur_pan = pan;
+      // ALL loads first, one wait, then the affine (coefficients staged in LDS once per workgroup): written as the obvious loop - load,
+      // convert, next - the compiler waits for every load in turn and a reload is a chain of 2 NKK memory round trips
 #pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-        const int k0 = kk * 32 + g * 8;
-        const bool kok = k0 < p.K;                                      // K is a multiple of 8
-        float4 sa, sb, ta, tb;
-        if (bnrelu) {
-          const unsigned po = kok ? (unsigned)(k0 * 4) : OOB;
-          sa = bldf(srdS, po); sb = bldf(srdS, po == OOB ? OOB : po + 16);
-          ta = bldf(srdT, po); tb = bldf(srdT, po == OOB ? OOB : po + 16);
-        }
+      for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int m = m0 + i * 16 + l16;
-          uint4 v = bld(srdX, (kok && m < p.M) ? (unsigned)m * (unsigned)(p.ldx * 2) + (unsigned)(k0 * 2) : OOB);
-          if (bnrelu) v = bnrelu8(v, sa, sb, ta, tb);
-          if (!kok) v = make_uint4(0, 0, 0, 0);                         // columns past K multiply (finite) weights of the next row: force exact zeros
+          const int m = m0 + i * 16 + l16, k0 = kk * 32 + g * 8;
+          const uint4 v = bld(srdX, (k0 < p.K && m < p.M) ? (unsigned)m * (unsigned)(p.ldx * 2) + (unsigned)(k0 * 2) : OOB);   // K is a multiple of 8; past K: zeros
           xr[i][kk] = __builtin_bit_cast(bf16x8, v);
         }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (also: the counted wait below assumes nothing but pieces and stores in flight)
+      if (bnrelu) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          const int k0 = kk * 32 + g * 8;
+          const float4 sa = *reinterpret_cast<const float4*>(coef + k0), sb = *reinterpret_cast<const float4*>(coef + k0 + 4);
+          const float4 ta = *reinterpret_cast<const float4*>(coef + NKK * 32 + k0), tb = *reinterpret_cast<const float4*>(coef + NKK * 32 + k0 + 4);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            uint4 v = bnrelu8(__builtin_bit_cast(uint4, xr[i][kk]), sa, sb, ta, tb);
+            if (k0 >= p.K) v = make_uint4(0, 0, 0, 0);                  // columns past K multiply (finite) weights of the next row: force exact zeros
+            xr[i][kk] = __builtin_bit_cast(bf16x8, v);
+          }
+        }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the counted wait below assumes nothing but pieces and stores in flight)
     }
     // this item's pieces have landed: behind them this wave issued exactly the previous item's 12 stores (nothing before the first item)
     RDM_STAMP(t0);
@@ -1049,7 +1060,7 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   if (panel) {
     static int n_cu = 0;
     if (!n_cu) { hipDeviceProp_t pr; int dev = 0; RDM_HIP_OK(hipGetDevice(&dev)); RDM_HIP_OK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
-    const int nkk = cdiv(a.K, 32), nks = (nkk + 1) / 2, lds = 2 * nks * PANEL_STEP + 4 * PANEL_EPI;
+    const int nkk = cdiv(a.K, 32), nks = (nkk + 1) / 2, lds = 2 * nks * PANEL_STEP + 4 * PANEL_EPI + nkk * 256;
     const long ob = ((long)(a.M - 1) * a.ldc + a.N) * 2;
     if (ob >= 0xFFFFFFFFL) { set_error("gemm_bf16: output extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
     a.o_bytes = (unsigned)ob;
@@ -1057,7 +1068,7 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
 #define RDM_GP(NKK_)                                                                                                                      \
   case NKK_: {                                                                                                                             \
     static bool attr_set = false;                                                                                                          \
-    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_bf16_kernel<NKK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((NKK_ + 1) / 2) * PANEL_STEP + 4 * PANEL_EPI)); attr_set = true; } \
+    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_bf16_kernel<NKK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((NKK_ + 1) / 2) * PANEL_STEP + 4 * PANEL_EPI + NKK_ * 256)); attr_set = true; } \
     hipLaunchKernelGGL((gemm_panel_bf16_kernel<NKK_>), grid, dim3(512), lds, s, a);                                                        \
   } break
     switch (nkk) { RDM_GP(1); RDM_GP(2); RDM_GP(3); RDM_GP(4); RDM_GP(5); RDM_GP(6); RDM_GP(7); RDM_GP(8); RDM_GP(9); RDM_GP(10); RDM_GP(11); default: break; }
