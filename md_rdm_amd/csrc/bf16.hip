@@ -1033,6 +1033,13 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   // tiles: 128 x 96 on big grids whose N is (nearly) a multiple of 96, 128 x 48 else; few pixels: 64 x 48 / 32 x 96 (more workgroups)
   const long t96 = (long)cdiv(a.M, 128) * cdiv(a.N, 96);
   const bool n96 = (double)cdiv(a.N, 96) * 96 <= 1.04 * a.N;
+  // Wave quantisation: 512 workgroups are resident (2 per CU).  dense_e3 (M = 8816, N = 1408) has 1035 tiles of 128 x 96 - three rounds,
+  // the third with 11 workgroups - but 897 of 128 x 112 (4 waves x 32 rows x 112 columns: 56 accumulators): two.  Cost = rounds x tile area.
+  const long t112 = (long)cdiv(a.M, 128) * cdiv(a.N, 112);
+  bool wide112 = cdiv(t112, 512L) * 112 < cdiv(t96, 512L) * 96 && t96 <= 4096;
+#ifdef RDM_DEV_VARIANTS
+  if (g_variant == 304) wide112 = false;
+#endif
   // few pixels (decoder: 640 rows) and a long K: split K over grid.z so the chip is not left to ~80 workgroups
   int split = 1;
   const long small_blocks = (long)cdiv(a.M, 32) * cdiv(a.N, 96);
@@ -1047,6 +1054,7 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
     dim3 grid(cdiv(a.N, NT_ * 16 * WN_), cdiv(a.M, MT_ * 16 * WM_), split);                                                                 \
     if (out_f32) hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, NS_, true>), grid, dim3(256), 0, s, a);                      \
     else hipLaunchKernelGGL((gemm_bf16_kernel<MT_, NT_, WM_, WN_, BK_, NS_, false>), grid, dim3(256), 0, s, a);                             \
+    RDM_CENSUS("gemm_bf16_kernel/%dx%d%s", MT_ * 16 * WM_, NT_ * 16 * WN_, split > 1 ? "/splitK" : "");                                     \
   } while (0)
   // (measured at M = 2280: 64x48 / 64x96 / 128x48 / 128x96 tiles and 2 vs 4 register stages all land at 21-26 us - the kernel is
   // bound by instruction issue, ~140 non-MFMA instructions per 64-deep step of which the BN-ReLU staging transform is the largest part)
@@ -1074,7 +1082,8 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
     switch (nkk) { RDM_GP(1); RDM_GP(2); RDM_GP(3); RDM_GP(4); RDM_GP(5); RDM_GP(6); RDM_GP(7); RDM_GP(8); RDM_GP(9); RDM_GP(10); RDM_GP(11); default: break; }
 #undef RDM_GP
     RDM_CENSUS("gemm_panel_bf16_kernel/nkk%d", cdiv(a.K, 32));
-  } else if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64, 2);
+  } else if (t96 >= 512 && wide112) RDM_G(2, 7, 4, 1, 64, 2);
+  else if (t96 >= 512 && n96) RDM_G(4, 3, 2, 2, 64, 2);
   else if ((long)cdiv(a.M, 128) * cdiv(a.N, 48) >= 512) RDM_G(2, 3, 4, 1, 64, 2);
   else if (a.M > 1024) RDM_G(2, 3, 2, 2, 64, 2);                         // 64 x 96
   else RDM_G(1, 3, 2, 2, 64, 2);                                         // 32 x 96

@@ -225,7 +225,8 @@ def test_conv3x3_act_bf16_operator(dev, op_census, B, H, W, Cc):
 
 
 @pytest.mark.parametrize("M,K,N,ld_pad", [(34656, 144, 2752, 48), (2280, 1056, 736, 96), (285, 2064, 736, 48), (80, 2160, 384, 48),
-                                          (34656, 96, 2752, 0), (20001, 336, 2736, 96), (8200, 240, 1040, 48), (24000, 352, 1100, 0), (34656, 288, 2752, 0)])
+                                          (34656, 96, 2752, 0), (20001, 336, 2736, 96), (8200, 240, 1040, 48), (24000, 352, 1100, 0), (34656, 288, 2752, 0),
+                                          (8816, 456, 1392, 48)])
 def test_gemm_bf16_act_operator(dev, op_census, M, K, N, ld_pad):
     """rdm_gemm_bf16_act: bf16(relu((relu(X*scale+shift) @ W^T) * out_scale + out_shift)) - the consumer's BatchNorm + ReLU applied to the
     f32 accumulator before the single bf16 rounding; direct epilogue and (few rows) the K-split + reduction path."""
@@ -247,6 +248,8 @@ def test_gemm_bf16_act_operator(dev, op_census, M, K, N, ld_pad):
         err = (out[:, :N].float() - want).abs().max().item()
         assert err <= 6e-3 * want.abs().max().item(), (use_ws, err, want.abs().max().item())
         assert torch.isnan(out[:, N:].float()).all()
+    if (M, K) == (8816, 456):                                    # dense_e3: the 128 x 112 tile (two rounds of workgroups instead of three)
+        assert "gemm_bf16_kernel/128x112" in _lib.census()
     if ((M + 255) // 256) * ((N + 95) // 96) >= 1024:            # the persistent panel kernel (dense_e2 shapes) ran
         assert any(k.startswith("gemm_panel_bf16_kernel/") for k in _lib.census())
 
