@@ -352,9 +352,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 #endif
 }
 
-template <int EPI, bool BNRELU>
+template <int EPI, bool BNRELU, int MT = 8>      // MT = 8: 256 x 128 macro tile; MT = 6: 192 x 128 (chosen where it fills the workgroup rounds better)
 __global__ __launch_bounds__(256, 2) void conv1x1_dma256_kernel(FwdArgs p) {
-  constexpr int MT = 8, NT = 4, BM = 256, BN = 128, NBUF = 3, NA = BM / 16 / 4, NB = BN / 16 / 4;      // 1-KiB pieces (16 rows x 64 B) per wave and slab: 4 + 2
+  constexpr int NT = 4, BM = MT * 32, BN = 128, NBUF = 3, NA = BM / 16 / 4, NB = BN / 16 / 4;      // 1-KiB pieces (16 rows x 64 B) per wave and slab: 4 (3) + 2
   constexpr int SLAB = (BM + BN) * BK + (BNRELU ? 512 : 0);                         // + one piece each for the slab's 16 scale / 16 shift values
   __shared__ __attribute__((aligned(1024))) float smem[NBUF * SLAB];               // ONE object (a second one makes hipcc drain vmcnt before every ds_read)
   float* const sm = smem;
@@ -410,12 +410,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma256_kernel(FwdArgs p) {
     f32x4 b4[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Bs(buf) + (wcol + j * 16 + l16) * BK + sl);
+    constexpr int MH = MT / 2;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                        // the A fragments in two halves: 16 + 16 fragment registers beside 128 accumulators
-      f32x4 a4[4];
+      f32x4 a4[MH];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a4[i] = *reinterpret_cast<const f32x4*>(As(buf) + (wrow + (h * 4 + i) * 16 + l16) * BK + sl);
+      for (int i = 0; i < MH; ++i) {
+        a4[i] = *reinterpret_cast<const f32x4*>(As(buf) + (wrow + (h * MH + i) * 16 + l16) * BK + sl);
         if (BNRELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) a4[i][e] = fmaxf(fmaf(a4[i][e], sc[e], sh[e]), 0.f);
@@ -424,9 +425,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma256_kernel(FwdArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MH; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], b4[j][e], acc[h * 4 + i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[h * MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][e], b4[j][e], acc[h * MH + i][j], 0, 0, 0);
     }
   }
   conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, wcol, l16, g);
@@ -1236,11 +1237,17 @@ static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue e
   // the two are level (109.5 vs 110.6 at K = 336), so the 128 x 96 register-staged kernel stays there.
   if (!taps && !b_kstrided && split == 1 && (epi == EPI_STORE || epi == EPI_STORE_STATS) && !a.add_out && a.bias == nullptr && a.M >= 16384 && a.M < 32768 &&
       a.N >= 512 && g_variant != 38) {
-    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 256), 1);
+    // 512 workgroups are resident (2 per CU): dense_e3 at B = 16 has 759 tiles of 256 x 128 - a full round and a half-empty one - but 1012
+    // of 192 x 128: two nearly full rounds of workgroups that are a quarter shorter.  Cost = rounds x tile rows.
+    const long t256 = (long)cdiv(a.N, 128) * cdiv(a.M, 256), t192 = (long)cdiv(a.N, 128) * cdiv(a.M, 192);
+    const bool m192 = cdiv(t192, 512L) * 192 < cdiv(t256, 512L) * 256 && g_variant != 39;
+    dim3 grid(cdiv(a.N, 128), cdiv(a.M, m192 ? 192 : 256), 1);
     const bool bn = a.a_scale != nullptr;
-    RDM_CENSUS("conv1x1_dma256_kernel/%s/bn%d", epi_name(epi), bn ? 1 : 0);
-    if (epi == EPI_STORE) { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE, false>), grid, dim3(256), 0, s, a); }
-    else { if (bn) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_STORE_STATS, false>), grid, dim3(256), 0, s, a); }
+    RDM_CENSUS("conv1x1_dma256_kernel/%s/bn%d%s", epi_name(epi), bn ? 1 : 0, m192 ? "/m192" : "");
+#define RDM_D256(EPI_, BN_) do { if (m192) hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_, BN_, 6>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv1x1_dma256_kernel<EPI_, BN_, 8>), grid, dim3(256), 0, s, a); } while (0)
+    if (epi == EPI_STORE) { if (bn) RDM_D256(EPI_STORE, true); else RDM_D256(EPI_STORE, false); }
+    else { if (bn) RDM_D256(EPI_STORE_STATS, true); else RDM_D256(EPI_STORE_STATS, false); }
+#undef RDM_D256
     RDM_LAUNCH_OK();
     return 0;
   }

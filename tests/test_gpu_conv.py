@@ -281,13 +281,13 @@ def test_halo3x3_256px_forward_and_dgrad_vs_float64(case):
     _RAN.add(("halo", case))
 
 
-@pytest.mark.parametrize("cout", [1392, 528])
-@pytest.mark.parametrize("cin", [192, 240, 720, 912])
+@pytest.mark.parametrize("cin,cout", [(192, 1392), (240, 1392), (720, 1392), (912, 1392), (192, 528), (240, 528), (720, 528), (912, 528), (240, 2736)])
 def test_conv1x1_dma256_kernel_vs_float64(cin, cout):
     """conv1x1_dma256_kernel (16 384 <= pixels < 32 768, >= 512 outputs: dense_e3's bottleneck, RDM_Net.py:528) vs an f64 matmul:
     K a multiple of 32 (192) and with a 16-channel tail (240, 720, 912), ragged last pixel tile (17 632 = 68 x 256 +
     224) and channel tile (1392 = 10 x 128 + 112, 528 = 4 x 128 + 16), BN-ReLU coefficients by DMA on / off, STORE and STORE_STATS, and NaN
-    in the channels BEHIND the contracted prefix of the input buffer."""
+    in the channels BEHIND the contracted prefix of the input buffer.  The launcher takes 192 x 128 tiles where they fill the rounds of 512
+    resident workgroups better (1392 / 528 outputs here: 17 632 = 91 x 192 + 160) and 256 x 128 otherwise (2736 outputs)."""
     from md_rdm_amd import _lib
     from md_rdm_amd._lib import ConvDesc, check, ptr, stream
     L = _lib.lib()
@@ -306,7 +306,10 @@ def test_conv1x1_dma256_kernel_vs_float64(cin, cout):
         a = (torch.relu(x[:, :cin] * sc + sh) if bn else x[:, :cin]).double()
         want = a @ w.double().t()
         for stats in (True, False):
-            key = "conv1x1_dma256_kernel/%s/bn%d" % ("STORE_STATS" if stats else "STORE", int(bn))
+            nt, cd = (cout + 127) // 128, lambda a, b: (a + b - 1) // b
+            m192 = cd(nt * cd(M, 192), 512) * 192 < cd(nt * cd(M, 256), 512) * 256          # the launcher's rule
+            assert m192 == (cout != 2736)
+            key = "conv1x1_dma256_kernel/%s/bn%d%s" % ("STORE_STATS" if stats else "STORE", int(bn), "/m192" if m192 else "")
             before = _lib.census().get(key, 0)
             y = torch.full((M, cout), float("nan"), device=dev)
             ssum = torch.zeros(cout, dtype=torch.float64, device=dev)
