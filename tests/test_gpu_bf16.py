@@ -117,7 +117,7 @@ def test_bf16_is_inference_only_and_tracks_weight_updates(dev):
 
 @pytest.mark.parametrize("M,K,N,prologue,bias,ld_pad", [(1000, 96, 2736, True, False, 48), (34656, 336, 96, True, False, 0), (640, 2208, 180, False, True, 0),
                                                         (2280, 1056, 720, True, False, 96), (77, 160, 96, False, True, 0), (640, 1632, 384, True, False, 576),
-                                                        (80, 2160, 384, True, False, 48)])
+                                                        (80, 2160, 384, True, False, 48), (34656, 96, 1056, True, False, 48), (33000, 208, 1060, False, False, 0)])
 def test_gemm_bf16_operator(dev, M, K, N, prologue, bias, ld_pad):
     """rdm_gemm_bf16: out = bias + relu(X*scale+shift) @ W^T on bf16 operands vs torch f32 on the same bf16-rounded operands."""
     from md_rdm_amd import _lib
