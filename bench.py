@@ -352,10 +352,11 @@ def bench_fwd_bf16(args):
         cpu = cpu_baseline_forward(H, W)
     out_line = None
     if rank == 0:
-        out_line = {"metric": "depth-maps/sec NYU 228x304 batch=8 forward bf16", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
+        name = "NYU 228x304" if (H, W) == (228, 304) else ("KITTI 352x1216" if (H, W) == (352, 1216) else f"{H}x{W}")
+        out_line = {"metric": f"depth-maps/sec {name} batch={B} forward bf16", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                     "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                    "config": {"workload": f"NYU-v2 {H}x{W} batch={B}/GPU forward-only bf16 (eval-mode DepthEstimationNet.forward: conv stack + DORN head + decomposition tail)",
+                    "config": {"workload": f"{name} batch={B}/GPU forward-only bf16 (eval-mode DepthEstimationNet.forward: conv stack + DORN head + decomposition tail)",
                                "global_batch": B * world, "parallelism": f"replicas{world}"},
                     "roofline": roof, "cpu_baseline": cpu}
     if world > 1:
