@@ -126,6 +126,15 @@ int rdm_conv2d_dgrad_ex(const rdm_conv_desc* d, const float* dy, const float* w_
 int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 
+/* Split-precision ("bf16x3") gradient kernels (csrc/xsplit.hip) for the autograd-generated weight / input gradients of the dense layers with
+ * many pixels (torchvision _DenseLayer.conv1 / conv2 reached from network/RDM_Net.py:526,528).  Same operands and meaning as the _ex entry
+ * points above; every float32 operand is split into two bf16 pieces at staging time and each product is formed as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores with float32 accumulation (error ~5e-6 of the result's maximum; the exact-f32
+ * MFMA kernels: ~1e-6).  Gradients only - the forward pass never goes through these.  RDM_ERR_UNSUPPORTED for shapes without such a kernel
+ * (1x1: 96 <= in_c <= 1536, in_c a multiple of 48). */
+int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
+                        float* dw_packed, int32_t split_k, rdm_stream_t stream);
+
 /* The 3x3 / stride 1 / pad 1 convolution with <= 48 outputs (torchvision _DenseLayer.conv2 reached from network/RDM_Net.py:144,526-530)
  * as Winograd F(2x2, 3x3) on the f32 MFMA path: 2.25x fewer multiply-adds than rdm_conv2d_fwd for the same result up to float32
  * rounding (tests/test_gpu_wino.py holds it to the same 2e-5 against a float64 evaluation).  Same operands and meaning as

@@ -11,6 +11,7 @@
 #include "elementwise.h"
 #include "bf16.h"
 #include "wino.h"
+#include "xsplit.h"
 
 namespace rdm {
 long long g_launches = 0;
@@ -204,6 +205,25 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.split_k = split_k;
   return launch_conv_wgrad(a, stream);
+}
+
+int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
+                        int32_t split_k, rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad_x3: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(dy && x && dw, "conv2d_wgrad_x3: NULL operand");
+  RDM_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "conv2d_wgrad_x3: bn_scale and bn_shift go together");
+  WgradArgs a{};
+  a.g = g; a.G = dy; a.ldg = d->out_ld; a.N = d->out_c;
+  a.Xs = x; a.ldx = d->in_ld; a.C = d->in_c; a.x_scale = bn_scale; a.x_shift = bn_shift;
+  a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.split_k = split_k;
+  a.xsplit = 1;
+  if (d->kh == 1 && d->kw == 1) return launch_xs_wgrad1x1(a, stream);
+  set_error("conv2d_wgrad_x3: no split-precision kernel for a %dx%d convolution", d->kh, d->kw);
+  return RDM_ERR_UNSUPPORTED;
 }
 
 size_t rdm_conv3x3_wino_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k) {

@@ -26,6 +26,7 @@
 
 #include "rdm_common.h"
 #include "elementwise.h"
+#include "xsplit.h"
 
 namespace rdm {
 
@@ -986,14 +987,16 @@ struct ProfScope {
   ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind, bytes}); } }
 };
 // per-kernel breakdown of the last profile_read()
-constexpr int PROF_KINDS = 13;
+constexpr int PROF_KINDS = 17;
 const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
     "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel",
     "gemm_bf16_kernel (1x1 forward, bf16 MFMA)", "conv3x3_bf16_kernel (3x3 forward, bf16 MFMA)",
     "conv3x3_wino_fwd_kernel (Winograd F(2x2,3x3) forward; FLOPs = the direct convolution's)",
     "conv3x3_wino_wgrad_kernel (Winograd F(3x3,2x2) weight gradient; FLOPs = the direct convolution's)",
-    "gemm_panel_bf16_kernel (short-K 1x1 forward, persistent panels, bf16 MFMA)", "conv3x3_act_bf16_kernel (3x3 forward on an activated input, LDS-DMA, bf16 MFMA)"};
+    "gemm_panel_bf16_kernel (short-K 1x1 forward, persistent panels, bf16 MFMA)", "conv3x3_act_bf16_kernel (3x3 forward on an activated input, LDS-DMA, bf16 MFMA)",
+    "xs_wgrad1x1_kernel (1x1 weight gradient, bf16x3 split MFMA; FLOPs = the f32 product's)", "xs_dgrad3x3_kernel (3x3 input gradient, bf16x3 split MFMA; FLOPs = the f32 product's)",
+    "xs_wgrad3x3_kernel (3x3 weight gradient, bf16x3 split MFMA; FLOPs = the f32 product's)", "xs_dgrad1x1_kernel (1x1 input gradient, bf16x3 split MFMA; FLOPs = the f32 product's)"};
 double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS], g_kind_bytes[PROF_KINDS];
 int g_kind_n[PROF_KINDS];
 }  // namespace
@@ -1318,6 +1321,8 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
                       a.g.H == a.g.Ho && a.g.W == a.g.Wo);
   const int ntaps = taps ? a.g.KH * a.g.KW : 1;
   const long Mpix = (long)a.g.B * a.g.Ho * a.g.Wo;
+  // split-precision (bf16x3) kernel where the caller allows it: long contractions only (the plan's many-pixel blocks)
+  if (a.xsplit && !t_deterministic && !taps && Mpix >= 8192 && xs_wgrad1x1_supported(a)) return launch_xs_wgrad1x1(a, s);
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   // a ragged last column tile of the 128 x 96 config wastes up to 25 % of the MFMAs (C = 144: 2 x 96); 256 x 48 tiles fit every

@@ -127,6 +127,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
   long n_items;                               // set by the launcher: column tiles x row tiles x splits
   unsigned g_bytes, x_bytes;                  // set by the launcher: addressable extents of G / Xs
   int xcd_flat;                               // 1: keep the hardware block order (A/B switch)
+  int xsplit;                                 // 1: the split-precision (bf16x3) kernels of xsplit.hip may serve this launch (gradients only)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);

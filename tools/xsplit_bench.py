@@ -1,0 +1,58 @@
+"""In-process A/B of the split-precision (bf16x3) gradient kernels (csrc/xsplit.hip) against the exact-f32 MFMA kernels they replace, through the
+C ABI, on the network's shapes, with the error of both against a float64 product.
+
+    python tools/xsplit_bench.py [wg1] [reps]
+"""
+import ctypes as C, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from md_rdm_amd import _lib
+from md_rdm_amd._lib import ConvDesc, ptr, stream, check
+L = _lib.lib()
+dev = torch.device("cuda")
+which = sys.argv[1] if len(sys.argv) > 1 else "wg1"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+
+
+def timeit(fns):
+    res = {k: [] for k in fns}
+    for rnd in range(4):
+        for k, fn in fns.items():
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps): fn()
+            torch.cuda.synchronize()
+            res[k].append((time.perf_counter() - t0) / reps)
+    return {k: min(v) for k, v in res.items()}
+
+
+def wg1(B, H, W, Cb, cin, ld):
+    M = B * H * W
+    g = torch.Generator(device="cpu").manual_seed(cin)
+    X = torch.randn(M, ld, device=dev)
+    dZ = torch.randn(M, Cb, device=dev)
+    sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.3
+    d = ConvDesc(B, H, W, cin, ld, Cb, Cb, 1, 1, 1, 1, 0, 0)
+    dW = torch.zeros(Cb, cin, device=dev)
+    def f32(): check(L.rdm_conv2d_wgrad(C.byref(d), ptr(dZ), ptr(X), ptr(sc), ptr(sh), ptr(dW), stream()))
+    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(dZ), ptr(X), ptr(sc), ptr(sh), ptr(dW), 0, stream()))
+    # error vs float64 on a slice of the output rows (the full product is 2 x 69312 x 2736 x 336 flops in f64 on the GPU: fine)
+    a = torch.relu(X[:, :cin].double() * sc.double() + sh.double())
+    want = dZ.double().t() @ a
+    errs = {}
+    for k, fn in (("f32", f32), ("x3", x3)):
+        dW.zero_(); fn(); torch.cuda.synchronize()
+        errs[k] = ((dW.double() - want).abs().max() / want.abs().max()).item()
+    del a, want
+    t = timeit({"f32": f32, "x3": x3})
+    fl = 2.0 * M * Cb * cin
+    by = 4.0 * M * (Cb + cin)
+    print(f"wg1 M={M} N={Cb} C={cin}: f32 {t['f32']*1e3:.3f} ms {fl/t['f32']/1e12:.0f} TF err {errs['f32']:.1e} | x3 {t['x3']*1e3:.3f} ms {fl/t['x3']/1e12:.0f} TF-equiv "
+          f"({by/t['x3']/1e12:.2f} TB/s algorithmic) err {errs['x3']:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
+
+
+if which in ("wg1", "all"):
+    for cin in (96, 144, 192, 240, 288, 336):
+        wg1(16, 57, 76, 2736, cin, 384)
+    for cin in (192, 336, 480, 720):
+        wg1(16, 29, 38, 1392, cin, 768)
