@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--workload", default="train", choices=["train", "fwd_bf16"],
                     help="train = the headline metric (BASELINE configs[2]); fwd_bf16 = BASELINE configs[1], batch=8 forward-only bf16")
+    ap.add_argument("--backward-precision", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="bf16x3 (default, what the package ships): the gradient GEMMs of dense_e2 / dense_e3 on the split-precision kernels; f32: exact-f32 MFMA everywhere")
     ap.add_argument("--no-extra-configs", action="store_true", help="headline line only (skip BASELINE configs[1] and configs[4] at N=1)")
     args = ap.parse_args()
     if args.workload == "fwd_bf16":
@@ -135,6 +137,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         L.rdm_debug_variant(int(os.environ["RDM_VARIANT"]))
 
     model = DepthEstimationNet()
+    model.backward_precision = args.backward_precision
     filler.fill_state_dict(model.state_dict())
     model = model.to(dev)
     model.train()
@@ -195,7 +198,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
         achieved = algo / (ms.value * 1e-3) / 1e12
         per_kernel = []
-        for kind in range(11):
+        for kind in list(range(11)) + [13, 14, 15, 16]:
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:

@@ -277,9 +277,13 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *   RDM_NET_OPT_JOIN_PER_SEGMENT rdm_net_backward_stage orders the library's side stream (weight gradients) before the caller's stream at the
  *                                end of each of the 4 SEGMENTS only, not after every stage: for callers that do not consume gradients
  *                                stage by stage (no data-parallel exchange).  The gradients of a segment are complete on the caller's
- *                                stream once its last stage has returned. */
+ *                                stream once its last stage has returned.
+ *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 8 192 pixels (dense_e2 / dense_e3 at the headline
+ *                                geometry) run the split-precision bf16x3 kernels (rdm_conv2d_*_x3, csrc/xsplit.hip) instead of the exact-f32
+ *                                MFMA kernels: gradients agree to ~5e-6 of a tensor's maximum, the forward pass is untouched.  Ignored in
+ *                                deterministic mode. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -186,6 +186,8 @@ struct NetImpl {
   int opt_no_wino = 0;         // RDM_NET_OPT_DIRECT_3X3: keep the direct implicit-GEMM kernels everywhere (A/B and tests)
   int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
   int opt_prezeroed = 0;       // RDM_NET_OPT_GRADS_PREZEROED: every gradient tensor is zero when backward stage 0 starts
+  int opt_split_bwd = 0;       // RDM_NET_OPT_SPLIT_BWD: the backward GEMMs of the many-pixel blocks run the split-precision (bf16x3) kernels of xsplit.hip
+  bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= 8192; }
   // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
   struct Bf16Layer { size_t w1, w3, bn1, bn2; };
   std::vector<Bf16Layer> bfl[4];
@@ -619,6 +621,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       w.G = dZ; w.ldg = cb; w.N = cb;
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
+      w.xsplit = n.xs_block(b);
       if ((rc = launch_conv_wgrad(w, side))) return rc;
       RDM_HIP_OK(hipEventRecord(n.ev_dz[par], side));
       n.dz_busy[par] = true;
@@ -729,6 +732,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
+  else if (option == RDM_NET_OPT_SPLIT_BWD) n->opt_split_bwd = value != 0;
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }
