@@ -134,6 +134,12 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * (1x1: 96 <= in_c <= 1536, in_c a multiple of 48). */
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
+/* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
+ * sums when mask_x is given).  The workspace receives the split weights in MFMA-fragment order (re-formed on every call). */
+size_t rdm_conv3x3_dgrad_x3_workspace_bytes(int32_t in_c);
+int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
+                         int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,
+                         size_t workspace_bytes, rdm_stream_t stream);
 
 /* The 3x3 / stride 1 / pad 1 convolution with <= 48 outputs (torchvision _DenseLayer.conv2 reached from network/RDM_Net.py:144,526-530)
  * as Winograd F(2x2, 3x3) on the f32 MFMA path: 2.25x fewer multiply-adds than rdm_conv2d_fwd for the same result up to float32

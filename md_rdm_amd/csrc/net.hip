@@ -19,6 +19,7 @@
 #include "elementwise.h"
 #include "bf16.h"
 #include "wino.h"
+#include "xsplit.h"
 
 namespace rdm {
 
@@ -178,6 +179,7 @@ struct NetImpl {
   int wino_split[4] = {1, 1, 1, 1};
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
+  size_t xsW = 0, xsWBytes = 0;
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
@@ -313,6 +315,10 @@ struct NetImpl {
       }
     winoVy = a.take<float>(winoVyFloats);
     winoQ = a.take<float>(winoQFloats);
+    // split-precision backward (xsplit.hip): fragment-order split weights of the layer whose 3x3 input gradient is running (main stream)
+    for (int b = 0; b < 4; ++b)
+      if (bg[b].M >= 8192) xsWBytes = std::max(xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb));
+    xsW = a.take<unsigned char>(xsWBytes);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
     for (int b = 0; b < 4; ++b) {
@@ -603,7 +609,9 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     d.Wt = w2p; d.wtap = (long)GROWTH * cb; d.ldw = cb;
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
-    if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
+    if (n.xs_block(b) && xs_dgrad3x3_supported(d)) {
+      if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s))) return rc;
+    } else if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
     // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
     // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
     if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,

@@ -5,4 +5,9 @@
 namespace rdm {
 bool xs_wgrad1x1_supported(const WgradArgs& a);
 int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s);      // same operands and meaning as launch_conv_wgrad for a 1x1 / stride 1 convolution
+// 3x3 / stride 1 / pad 1 input gradient with 48 gradient channels (FwdArgs as launch_conv_fwd takes them for a dgrad: A = output gradient, Wt = packed
+// weights [tap][48][N], out = input gradient [M][N]); epi = EPI_STORE or EPI_MASK_STATS; ws = xs_dgrad3x3_workspace_bytes(N) bytes of scratch
+bool xs_dgrad3x3_supported(const FwdArgs& a);
+size_t xs_dgrad3x3_workspace_bytes(int Cb);
+int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace rdm

@@ -22,6 +22,7 @@
 //  * staging = global -> registers (next slab in flight under the MFMAs) -> BatchNorm + ReLU -> split -> LDS; one image set, two
 //    barriers per slab, two workgroups per CU so one's staging runs beside the other's MFMAs.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "rdm_common.h"
 #include "elementwise.h"
@@ -265,6 +266,238 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad1x1_kernel(XsWgradArgs p) {
   }
 }
 
+
+// =============================================================================================
+// 3x3 / stride 1 / pad 1 INPUT gradient of the dense layers' conv2 (48 gradient channels -> Cb = bn_size * growth bottleneck channels):
+//     dZ[m][c] = sum_{tap, n} go[pix(m, tap)][n] * W[tap][n][c],   pix(m, (r, q)) = (y + 1 - r, x + 1 - q),
+// optionally gated by the ReLU of the forward value (fma(Y[m][c], xs[c], xt[c]) > 0) with the two BatchNorm-backward sums of the gated
+// result (sum dz, sum dz * Y) accumulated per channel - the EPI_MASK_STATS epilogue of igemm.hip.
+// GEMM view: 432 = 9 x 48 contracted values per output, i.e. 13.5 MFMA k-steps of 32; a lane's 8-value chunk of a k-step never straddles
+// a tap (48 = 6 x 8), so chunk ch = 4 j + g of step j belongs to tap ch / 6, channels 8 (ch % 6) ..
+//  * a workgroup owns 192 consecutive pixels.  Their gradient tile (+ W + 1 pixels on either side, 48 channels) is split ONCE into two
+//    bf16 images [slot][48] in LDS and serves every output channel the workgroup computes: a fragment is one ds_read_b128 at (slot of
+//    the lane's pixel + the tap's shift); a tap that leaves the image reads slot 0, which holds zeros.  With 96-byte slots the 16
+//    lanes of a ds_read_b128 group (8 consecutive pixels of k-group g, 8 of g + 1: 16 bytes further) cover all 64 banks.
+//  * the weights arrive pre-split in FRAGMENT order (k_xs_pack_w3_dgrad: [16-channel tile][k-step][hi | lo][lane][8 bf16], one pass per
+//    layer and step over 4.7 MB); a wave owns 32 of the 128 output channels of a column tile and takes ITS fragments straight from
+//    global memory (L2) into registers, one k-step ahead - no LDS, no DMA, and therefore NO barrier in the main loop.
+//  * MFMA A operand = weights (rows = output channels), B operand = gradient (columns = pixels): a lane then holds 4 CONSECUTIVE
+//    channels of one pixel - the gate's Y read and the dZ store are 16-byte accesses, two of them side by side cover a pixel's 128-byte
+//    line - and every wave owns its 32 channels for ALL 192 pixels: the BatchNorm-backward sums need no cross-wave reduction.
+//  * a work item = (pixel tile, group of column tiles): the image staging and the address set-up are paid once per group.
+// =============================================================================================
+constexpr int XD_BM = 192, XD_MT = XD_BM / 16, XD_KSTEPS = 14, XD_SLOT = 96, XD_BN = 128, XD_EB = 6;
+
+struct XsDgrad3Args {
+  const float* G; int ldg;
+  const unsigned char* Wf;
+  float* out; int ldc;
+  const float* X; int ldx; const float* x_scale; const float* x_shift;
+  double* stat0; double* stat1;
+  int B, H, W, M, Cb;
+  int nslots, plane_bytes;                 // slot 0 = zeros, slot 1 + s = pixel m0 - (W + 1) + s, s < XD_BM + 2 (W + 1)
+  int mtiles, ctiles;                      // pixel tiles, 128-channel column tiles
+  unsigned g_bytes, w_bytes, x_bytes, o_bytes;
+};
+
+__global__ __launch_bounds__(256) void k_xs_pack_w3_dgrad(const float* __restrict__ w, long wtap, int ldw, int Cb, unsigned char* __restrict__ Wf) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(idx & 63);
+  const long r1 = idx >> 6;
+  const int j = (int)(r1 % XD_KSTEPS), ct = (int)(r1 / XD_KSTEPS);
+  if (ct >= Cb / 16) return;
+  const int c = ct * 16 + (lane & 15), g = lane >> 4;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * j + 8 * g + e, tap = k / 48, n = k - tap * 48;
+    v[e] = k < 432 ? w[(long)tap * wtap + (long)n * ldw + c] : 0.f;
+  }
+  u32x2 h0, l0, h1, l1;
+  split4(v[0], v[1], v[2], v[3], h0, l0);
+  split4(v[4], v[5], v[6], v[7], h1, l1);
+  unsigned char* dst = Wf + ((((long)ct * XD_KSTEPS + j) * 2) * 64 + lane) * 16;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<u32x4*>(dst + 1024) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char xs_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int W = p.W, HW = p.H * p.W;
+  // work items = (pixel tile, 128-channel column tile), column tile fastest; workgroup b takes the contiguous range [b T / G, (b + 1) T / G)
+  // of them (G = gridDim.x = every workgroup slot of the chip: all resident at once, balanced to +-1 item) and re-stages the gradient
+  // images only when its pixel tile changes
+  const int T = p.mtiles * p.ctiles;
+  const int it0 = (int)((long)blockIdx.x * T / gridDim.x), it1 = (int)((long)(blockIdx.x + 1) * T / gridDim.x);
+  unsigned char* const Ahi = xs_smem;
+  unsigned char* const Alo = xs_smem + p.plane_bytes;
+  const __amdgpu_buffer_rsrc_t srdG = xsrd(p.G, p.g_bytes), srdW = xsrd(p.Wf, p.w_bytes), srdX = xsrd(p.X, p.x_bytes);
+
+  // k-step j -> the lane's chunk: offset of (tap shift, 8-channel group), biased by +32768, two per register
+  unsigned dpk[XD_KSTEPS / 2];
+  const int hi2 = g >> 1;
+#pragma unroll
+  for (int j = 0; j < XD_KSTEPS; ++j) {
+    const int ch = 4 * j + g, tap = ch < 54 ? ch / 6 : 0, r = tap / 3, q = tap - 3 * r;
+    const unsigned d = (unsigned)(((1 - r) * W + (1 - q)) * XD_SLOT + (ch - 6 * (ch / 6)) * 16 + 32768);
+    if (j & 1) dpk[j >> 1] |= d << 16; else dpk[j >> 1] = d;
+  }
+  int base0 = 0; int vm[XD_MT / 3];                          // pixel tile i: image offset base0 + 16 * 96 * i; 9 validity bits at bit 10 * (i % 3) of vm[i / 3]
+  int cur_mt = -1, m0 = 0;
+  const unsigned wv = (unsigned)(lane * 16);
+  for (int it = it0; it < it1; ++it) {
+    const int mt = it / p.ctiles, tile = it - mt * p.ctiles;
+    if (mt != cur_mt) {
+      cur_mt = mt;
+      m0 = mt * XD_BM;
+      __syncthreads();                                          // every wave is past its reads of the previous images
+      // ---- gradient tile -> the two bf16 images ----
+      const int total4 = (p.nslots - 1) * 12, pbase = m0 - (W + 1);
+      for (int b0 = 0; b0 < total4; b0 += 256 * 6) {
+        f32x4 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int idx = b0 + u * 256 + tid, slot = idx / 12, quad = idx - slot * 12;
+          const int pix = pbase + slot;
+          const bool ok = idx < total4 && pix >= 0 && pix < p.M;
+          v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)(ok ? (unsigned)pix * (unsigned)(p.ldg * 4) + (unsigned)(quad * 16) : XOOB), 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int idx = b0 + u * 256 + tid, slot = idx / 12, quad = idx - slot * 12;
+          if (idx < total4) {
+            u32x2 hi, lo;
+            split4(v[u][0], v[u][1], v[u][2], v[u][3], hi, lo);
+            *reinterpret_cast<u32x2*>(Ahi + (slot + 1) * XD_SLOT + quad * 8) = hi;
+            *reinterpret_cast<u32x2*>(Alo + (slot + 1) * XD_SLOT + quad * 8) = lo;
+          }
+        }
+      }
+      if (tid < 24) *reinterpret_cast<u32x2*>(xs_smem + (tid % 12) * 8 + (tid / 12) * p.plane_bytes) = u32x2{0u, 0u};      // slot 0 of both planes
+      // ---- per lane: pixel tile i -> image offset of the pixel's slot (biased by -32768) and the validity of its 9 taps ----
+      base0 = (l16 + W + 1 + 1) * XD_SLOT - 32768;
+#pragma unroll
+      for (int i = 0; i < XD_MT; ++i) {
+        const int m = m0 + i * 16 + l16;
+        const bool ok = m < p.M;
+        const int b = m / HW, rem = m - b * HW, y = rem / W, x = rem - y * W;
+        int v = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int r = tap / 3, q = tap - 3 * r;
+          const bool valid = ok && (unsigned)(y + 1 - r) < (unsigned)p.H && (unsigned)(x + 1 - q) < (unsigned)W;
+          v |= valid ? (1 << tap) : 0;
+        }
+        if (i % 3 == 0) vm[i / 3] = v; else vm[i / 3] |= v << (10 * (i % 3));      // bit 9 of each field (the zero half-step 432 .. 447) stays clear
+      }
+      __syncthreads();                                          // the images are complete
+    }
+    const int ct16 = tile * (XD_BN / 16) + 2 * wave;            // this wave's two 16-channel tiles
+    if (ct16 * 16 >= p.Cb) continue;                            // (wave-uniform) ragged last column tile
+    asm volatile("" : "+v"(base0));                             // (keeps the 168 fragment addresses from being hoisted out of the item loop into registers)
+    f32x4 acc[XD_MT][2];
+#pragma unroll
+    for (int i = 0; i < XD_MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // weight fragments of k-step j: [t][hi | lo], 1 KiB each, one coalesced 16-byte load per lane (a tile past Cb reads as zeros)
+    bf16x8 wf[2][2][2];
+    auto load_w = [&](int j, bf16x8 (&w)[2][2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          w[t][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(wv + (unsigned)((ct16 + t) * (XD_KSTEPS * 2048))), j * 2048 + pl * 1024, 0));
+    };
+    // (the hardware range check looks at the VECTOR offset: the tile index travels there, so a tile past Cb reads as zeros)
+    const bool t1ok = (ct16 + 1) * 16 < p.Cb;
+    load_w(0, wf[0]);
+    // gradient fragments of (k-step j, pixel tile i): software pipeline - the pair of ds_read_b128 of tile i + 1 is issued BEFORE the six
+    // MFMAs of tile i (pinned: left alone, hipcc sinks every read next to its first use and the matrix pipe waits for LDS 12 times a step)
+    bf16x8 gq[2][2];
+    auto frag = [&](int j, int i, bf16x8 (&f)[2]) {
+      const int dj = (int)((dpk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+      const int tapj = (4 * j) / 6 + (((4 * j) % 6 == 4) ? hi2 : 0);      // == (4 j + g) / 6; 9 in the zero half-step -> never valid
+      const int a = (base0 + i * (16 * XD_SLOT) + dj) & __builtin_amdgcn_sbfe(vm[i / 3], (unsigned)(tapj + 10 * (i % 3)), 1u);
+      f[0] = *reinterpret_cast<const bf16x8*>(Ahi + a);
+      f[1] = *reinterpret_cast<const bf16x8*>(Alo + a);
+    };
+    frag(0, 0, gq[0]);
+#pragma unroll
+    for (int j = 0; j < XD_KSTEPS; ++j) {
+      if (j + 1 < XD_KSTEPS) load_w(j + 1, wf[(j + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < XD_MT; ++i) {
+        const int cur = (j * XD_MT + i) & 1;
+        if (i + 1 < XD_MT) frag(j, i + 1, gq[cur ^ 1]);
+        else if (j + 1 < XD_KSTEPS) frag(j + 1, 0, gq[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][1], gq[cur][0], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][0], gq[cur][1], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][0], gq[cur][0], acc[i][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue: D row = 4 g + r (channel), column = l16 (pixel): a lane owns channels c4 .. c4 + 3 of pixel m ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int c4 = (ct16 + t) * 16 + 4 * g;
+      const bool cok = t == 0 || t1ok;
+      f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
+      if (MASK && cok) { xs = *reinterpret_cast<const f32x4*>(p.x_scale + c4); xt = *reinterpret_cast<const f32x4*>(p.x_shift + c4); }
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      // (gate loads in buffer form: ONE 32-bit offset register, the pixel tile's row offset travels in the scalar offset; a pixel or channel
+      // tile past the end becomes an out-of-range vector offset and reads as zeros)
+      const unsigned vx = (unsigned)(m0 + l16) * (unsigned)(p.ldx * 4) + (unsigned)(c4 * 4);
+#pragma unroll
+      for (int i0 = 0; i0 < XD_MT; i0 += XD_EB) {
+        f32x4 xv[XD_EB];
+        if (MASK) {
+#pragma unroll
+          for (int u = 0; u < XD_EB; ++u)
+            xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (int)((cok && m0 + (i0 + u) * 16 + l16 < p.M) ? vx : XOOB), (i0 + u) * 16 * p.ldx * 4, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < XD_EB; ++u) {
+          const int i = i0 + u;
+          const bool ok = cok && m0 + i * 16 + l16 < p.M;
+          f32x4 v = acc[i][t];
+          if (MASK) {
+            const f32x4 x = xv[u];                                 // zeros where !ok: nothing of a dead element reaches the sums
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(x[e], xs[e], xt[e]) > 0.f ? v[e] : 0.f;
+            if (ok) { s0 += v; s1 += v * x; }
+          }
+          // (plain global stores ON PURPOSE: with buffer-form stores here, the shuffles and the exec-masked atomics of the statistics below
+          // left wrong values in lanes 12-15 of some stored registers on MI355X / ROCm 7.2 - measured, cause not established; the same
+          // epilogue with global_store_dwordx4 is exact)
+          if (ok) *reinterpret_cast<f32x4*>(p.out + (long)(m0 + i * 16 + l16) * p.ldc + c4) = v;
+        }
+      }
+      if (MASK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = s0[e], b = s1[e];
+          a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+          a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+          a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+          a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+          if (l16 == e) { s0[0] = a; s1[0] = b; }               // lane e of each 16 keeps channel c4 + e
+        }
+        if (l16 < 4 && cok) {
+          atomicAdd(p.stat0 + c4 + l16, (double)s0[0]);
+          atomicAdd(p.stat1 + c4 + l16, (double)s1[0]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool xs_wgrad1x1_supported(const WgradArgs& a) {
@@ -296,6 +529,62 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * a.C, 13);
   RDM_CENSUS("xs_wgrad1x1_kernel/%s/%s", a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1");
   hipLaunchKernelGGL(xs_wgrad1x1_kernel, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+size_t xs_dgrad3x3_workspace_bytes(int Cb) { return (size_t)(Cb / 16) * XD_KSTEPS * 2048; }
+
+static int xs_dgrad3_lds_bytes(int W) {
+  const int nslots = 1 + XD_BM + 2 * (W + 1);
+  const int plane = (nslots * XD_SLOT + 1023) & ~1023;
+  return 2 * plane;
+}
+
+bool xs_dgrad3x3_supported(const FwdArgs& a) {
+  const ConvGeom& g = a.g;
+  return g.KH == 3 && g.KW == 3 && g.SH == 1 && g.SW == 1 && g.PH == 1 && g.PW == 1 && g.H == g.Ho && g.W == g.Wo && g.dir == -1 && a.C == 48 &&
+         a.N % 16 == 0 && a.N >= 16 && xs_dgrad3_lds_bytes(g.W) <= 156 * 1024 && (g.W + 2) * XD_SLOT < 32768 && a.bias == nullptr && !a.accumulate && !a.add_out;
+}
+
+int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+  RDM_CHECK_ARG(xs_dgrad3x3_supported(a), "split-precision 3x3 dgrad: needs a 3x3 / stride 1 / pad 1 convolution with 48 gradient channels, N (%d) a multiple of 16, W (%d) <= 339", a.N, a.g.W);
+  RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 3x3 dgrad: plain or gate + statistics epilogue only");
+  RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 3x3 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
+  RDM_CHECK_ARG(epi != EPI_MASK_STATS || (a.X && a.x_scale && a.x_shift && a.stat0 && a.stat1 && a.ldx % 4 == 0 && ((uintptr_t)a.X & 15) == 0), "split-precision 3x3 dgrad: the gate needs X, scale, shift and both statistics");
+  RDM_CHECK_ARG(ws != nullptr && ((uintptr_t)ws & 15) == 0 && ws_bytes >= xs_dgrad3x3_workspace_bytes(a.N), "split-precision 3x3 dgrad: workspace too small or misaligned (%zu < %zu)", ws_bytes, xs_dgrad3x3_workspace_bytes(a.N));
+  const long M = a.M;
+  const long gb = ((M - 1) * a.lda + 48) * 4, ob = ((M - 1) * a.ldc + a.N) * 4, xb = a.X ? ((M - 1) * a.ldx + a.N) * 4 : 16;
+  if (gb >= 0xFFFFFFFFL || ob >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 3x3 dgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  const int Cb = a.N;
+  {
+    const long threads = (long)(Cb / 16) * XD_KSTEPS * 64;
+    hipLaunchKernelGGL(k_xs_pack_w3_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.wtap, a.ldw, Cb, static_cast<unsigned char*>(ws));
+    RDM_LAUNCH_OK();
+  }
+  XsDgrad3Args k{};
+  k.G = a.A; k.ldg = a.lda; k.Wf = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
+  k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
+  k.B = a.g.B; k.H = a.g.H; k.W = a.g.W; k.M = (int)M; k.Cb = Cb;
+  k.nslots = 1 + XD_BM + 2 * (a.g.W + 1);
+  k.plane_bytes = (k.nslots * XD_SLOT + 1023) & ~1023;
+  k.mtiles = cdiv(M, XD_BM); k.ctiles = cdiv(Cb, XD_BN);
+  k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad3x3_workspace_bytes(Cb); k.x_bytes = (unsigned)xb; k.o_bytes = (unsigned)ob;
+  const int lds = xs_dgrad3_lds_bytes(a.g.W);
+  // persistent workgroups: as many as are resident at once (2 per CU while two image pairs fit the 160 KB of LDS), each with an equal share of the items
+  const long items = (long)k.mtiles * k.ctiles;
+  const long slots = 256L * (lds <= 80 * 1024 ? 2 : 1);
+  void* prof = profile_begin(s, 2.0 * (double)M * Cb * 432.0, 14);
+  RDM_CENSUS("xs_dgrad3x3_kernel/%s", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  const dim3 grid((unsigned)std::min(items, slots));
+  if (epi == EPI_MASK_STATS) {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(xs_dgrad3x3_kernel<true>, grid, dim3(256), lds, s, k);
+  } else {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(xs_dgrad3x3_kernel<false>, grid, dim3(256), lds, s, k);
+  }
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;

@@ -70,3 +70,63 @@ def test_xs_wgrad1x1_rejects_unsupported_shapes():
     t = torch.zeros(64, 64, device=dev)
     d = ConvDesc(1, 8, 8, 64, 64, 64, 64, 1, 1, 1, 1, 0, 0)            # C = 64: not a multiple of 48
     assert L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(t), ptr(t), None, None, ptr(t), 0, stream()) < 0
+
+
+def _ref3x3_dgrad(gy, w9):
+    """gy (B,H,W,N) f64, w9 (9,N,C) -> dx (B*H*W, C): the definition (shifted-slice matmuls, zero padding 1)"""
+    import torch.nn.functional as F
+    B, H, W, N = gy.shape
+    gp = F.pad(gy, (0, 0, 1, 1, 1, 1))
+    dx = torch.zeros(B * H * W, w9.shape[2], dtype=torch.float64)
+    for r in range(3):
+        for q in range(3):
+            dx += gp[:, 2 - r:2 - r + H, 2 - q:2 - q + W, :].reshape(-1, N) @ w9[r * 3 + q]
+    return dx
+
+
+DGRAD3_CASES = [
+    # B, H, W, Cb, ldg (the 48 gradient channels sit in a wider block-gradient buffer)
+    (2, 57, 76, 336, 384),       # dense_e2's map (RDM_Net.py:526): 3 full column tiles + a 48-wide one, ragged last pixel tile
+    (6, 29, 38, 1392, 96),       # dense_e3 at its real width (RDM_Net.py:528): 14 x 96 + 48
+    (3, 9, 7, 96, 48),           # tiny rows: the halo spans several image rows and image boundaries inside one tile
+    (1, 66, 127, 192, 48),       # wide rows (LDS image 384 slots)
+]
+
+
+@pytest.mark.parametrize("case", DGRAD3_CASES, ids=[f"d3x3_{i}" for i in range(len(DGRAD3_CASES))])
+def test_xs_dgrad3x3_vs_float64(case):
+    """xs_dgrad3x3_kernel, plain and with the ReLU gate + BatchNorm-backward sums: image borders, batch wrap-around inside a tile, the
+    ragged last pixel tile and the 48-wide last column tile."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cb, ldg = case
+    N, M = 48, B * H * W
+    g = torch.Generator().manual_seed(5000 + Cb)
+    gyb = torch.randn(B, H, W, ldg, generator=g)
+    gy = gyb[..., ldg - N:].contiguous()                      # the layer's slice: the LAST 48 channels of the buffer row
+    w9 = torch.randn(9, N, Cb, generator=g) / (9 * N) ** 0.5
+    y = torch.randn(M, Cb, generator=g)
+    sc = torch.rand(Cb, generator=g) + 0.5
+    sh = torch.randn(Cb, generator=g) * 0.3
+    want = _ref3x3_dgrad(gy.double(), w9.double())
+    d = ConvDesc(B, H, W, Cb, Cb, N, ldg, 3, 3, 1, 1, 1, 1)
+    gyg, wg, yg, scg, shg = gyb.to(dev), w9.to(dev), y.to(dev), sc.to(dev), sh.to(dev)
+    gptr = C.c_void_p(gyg.data_ptr() + (ldg - N) * 4)
+    wsb = L.rdm_conv3x3_dgrad_x3_workspace_bytes(Cb)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dx = torch.full((M, Cb), float("nan"), device=dev)
+    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dx), Cb, None, 0, None, None, None, None, ptr(ws), wsb, stream()))
+    err = rel(dx.cpu().double(), want)
+    assert err < TOL, err
+    # gated: dz = dx * (y * sc + sh > 0); sums of dz and dz * y per channel
+    s0 = torch.zeros(Cb, dtype=torch.float64, device=dev)
+    s1 = torch.zeros_like(s0)
+    dz = torch.full((M, Cb), float("nan"), device=dev)
+    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dz), Cb, ptr(yg), Cb, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    gate = (y * sc + sh) > 0
+    wantz = want * gate
+    assert rel(dz.cpu().double(), wantz) < TOL
+    assert rel(s0.cpu(), wantz.sum(0)) < 1e-5 and rel(s1.cpu(), (wantz * y.double()).sum(0)) < 1e-5
+    _RAN.add(("xs_dgrad3x3", case))

@@ -51,6 +51,33 @@ def wg1(B, H, W, Cb, cin, ld):
           f"({by/t['x3']/1e12:.2f} TB/s algorithmic) err {errs['x3']:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
 
 
+def dg3(B, H, W, Cb):
+    M = B * H * W
+    Y = torch.randn(M, Cb, device=dev)
+    sc = torch.rand(Cb, device=dev) + 0.5; sh = torch.randn(Cb, device=dev) * 0.3
+    w3 = torch.randn(9, 48, Cb, device=dev) * 0.05
+    g48 = torch.randn(M, 48, device=dev)
+    dZ = torch.empty(M, Cb, device=dev)
+    s0 = torch.zeros(Cb, dtype=torch.float64, device=dev); s1 = torch.zeros_like(s0)
+    d3 = ConvDesc(B, H, W, Cb, Cb, 48, 48, 3, 3, 1, 1, 1, 1)
+    wsb = L.rdm_conv3x3_dgrad_x3_workspace_bytes(Cb)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    def f32(): check(L.rdm_conv2d_dgrad(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), stream()))
+    def x3(): check(L.rdm_conv3x3_dgrad_x3(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    outs = {}
+    for k, fn in (("f32", f32), ("x3", x3)):
+        fn(); torch.cuda.synchronize(); outs[k] = dZ[:4096].clone()
+    diff = ((outs["x3"] - outs["f32"]).abs().max() / outs["f32"].abs().max()).item()
+    t = timeit({"f32": f32, "x3": x3})
+    fl = 2.0 * M * Cb * 432
+    by = 4.0 * M * (2 * Cb + 48)
+    print(f"dg3 M={M} Cb={Cb}: f32 {t['f32']*1e3:.3f} ms {fl/t['f32']/1e12:.0f} TF | x3 {t['x3']*1e3:.3f} ms {fl/t['x3']/1e12:.0f} TF-equiv ({by/t['x3']/1e12:.2f} TB/s algorithmic) "
+          f"| x3 vs f32 kernel {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
+
+
+if which in ("dg3", "all"):
+    dg3(16, 57, 76, 2736)
+    dg3(16, 29, 38, 1392)
 if which in ("wg1", "all"):
     for cin in (96, 144, 192, 240, 288, 336):
         wg1(16, 57, 76, 2736, cin, 384)
