@@ -136,6 +136,10 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
  * sums when mask_x is given).  The workspace receives the split weights in MFMA-fragment order (re-formed on every call). */
+size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c);
+int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
+                         int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,
+                         size_t workspace_bytes, rdm_stream_t stream);      /* 1x1 / stride 1 (the dense layers' conv1): w_packed = [out_c][in_c] */
 size_t rdm_conv3x3_dgrad_x3_workspace_bytes(int32_t in_c);
 int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
                          int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,

@@ -227,6 +227,26 @@ int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   return launch_xs_dgrad3x3(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
 }
 
+size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c) { return out_c > 0 && in_c > 0 ? xs_dgrad1x1_workspace_bytes(out_c, in_c) : 0; }
+
+int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
+                         const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace, size_t workspace_bytes,
+                         rdm_stream_t stream) {
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(dy && w && dx, "conv1x1_dgrad_x3: NULL operand");
+  RDM_CHECK_ARG(!mask_x || (mask_scale && mask_shift && stat_a && stat_b), "conv1x1_dgrad_x3: mask needs scale, shift and both statistics");
+  ConvGeom gd{d->batch, g.Ho, g.Wo, d->in_h, d->in_w, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, -1};
+  FwdArgs a{};
+  a.g = gd; a.A = dy; a.lda = d->out_ld; a.C = d->out_c;
+  a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
+  a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
+  if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 768)"); return RDM_ERR_UNSUPPORTED; }
+  return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
+}
+
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
                         int32_t split_k, rdm_stream_t stream) {
   RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad_x3: split_k (%d) must be 0 (auto) .. 128", (int)split_k);

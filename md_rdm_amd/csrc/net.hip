@@ -317,7 +317,7 @@ struct NetImpl {
     winoQ = a.take<float>(winoQFloats);
     // split-precision backward (xsplit.hip): fragment-order split weights of the layer whose 3x3 input gradient is running (main stream)
     for (int b = 0; b < 4; ++b)
-      if (bg[b].M >= 8192) xsWBytes = std::max(xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb));
+      if (bg[b].M >= 8192) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
@@ -643,7 +643,9 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     e.Wt = F(T, L.conv1); e.wtap = 0; e.ldw = cin;
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
-    if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
+    if (n.xs_block(b) && xs_dgrad1x1_supported(e)) {
+      if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s))) return rc;
+    } else if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
     if ((rc = launch_bn_bwd_apply(G, g.ctot, dZ1, cin, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
                                   Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
       return rc;

@@ -10,4 +10,8 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s);      // same operands
 bool xs_dgrad3x3_supported(const FwdArgs& a);
 size_t xs_dgrad3x3_workspace_bytes(int Cb);
 int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s);
+// 1x1 / stride 1 input gradient (FwdArgs as for a dgrad: A = output gradient [M][C = contracted channels], Wt = weights [C][N], out = [M][N])
+bool xs_dgrad1x1_supported(const FwdArgs& a);
+size_t xs_dgrad1x1_workspace_bytes(int K, int C);
+int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace rdm

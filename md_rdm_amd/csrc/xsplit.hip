@@ -498,6 +498,200 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
   }
 }
 
+
+// =============================================================================================
+// 1x1 INPUT gradient of the dense layers' conv1:  dX[m][c] = sum_n dY[m][n] * W[n][c]  (n: the Cb bottleneck channels, contiguous in dY's
+// rows; c: the layer's input channels), optionally gated by the ReLU of the forward value with the BatchNorm-backward sums (EPI_MASK_STATS).
+//  * both operands live in LDS per 32-deep k-step as [row][32 k] bf16 images (64 B per row and plane, 16-byte chunks XOR-swizzled by
+//    ((row >> 2) & 1) << 1: the ds_read_b128 lane groups then cover all 64 banks): rows = pixels for the gradient, rows = output
+//    channels for the weights.  The gradient slab is staged global -> registers -> split -> LDS (next slab in flight under the MFMAs);
+//    the weights come pre-split AND pre-transposed ([plane][k-step][c][32 k], k_xs_pack_w1_dgrad) and are copied verbatim.
+//  * one 8-wave workgroup per CU: 2 wave columns x 4 wave rows; a wave owns <= 6 sixteen-channel tiles x <= 5 sixteen-pixel tiles.
+//    The tile height (16 .. 320 pixels) is chosen by the host so that the grid fills whole rounds of the 256 CUs.
+//  * MFMA A operand = weights (rows = channels), B = gradient (columns = pixels): 16-byte gate loads / stores as in the 3x3 kernel.
+// =============================================================================================
+constexpr int X1_MTW = 5, X1_NTW = 6, X1_BMMAX = 4 * X1_MTW * 16, X1_BNMAX = 2 * X1_NTW * 16;
+constexpr int X1_G_IMG = X1_BMMAX * 64, X1_W_IMG = X1_BNMAX * 64;           // one plane of one stage
+constexpr int X1_STAGE = 2 * X1_G_IMG + 2 * X1_W_IMG, X1_LDS = 2 * X1_STAGE;
+
+struct XsDgrad1Args {
+  const float* G; int ldg; int K;          // dY [M][ldg], K = Cb contracted channels
+  const unsigned char* Wp;                 // [plane][ksteps][C][64 B]
+  float* out; int ldc;
+  const float* X; int ldx; const float* x_scale; const float* x_shift;
+  double* stat0; double* stat1;
+  int M, C, ksteps;
+  int PT;                                  // 16-pixel tiles per workgroup
+  int mtiles, ctiles;                      // pixel tiles x column tiles (<= 12 sixteen-channel tiles each)
+  int ct_c0[4], ct_n[4];                   // column tile t: first 16-channel tile, number of 16-channel tiles
+  unsigned g_bytes, w_bytes, x_bytes;
+};
+
+__global__ __launch_bounds__(256) void k_xs_pack_w1_dgrad(const float* __restrict__ w, int ldw, int K, int C, int ksteps, unsigned char* __restrict__ Wp) {
+  // one thread per (k-step, c, 8-k chunk): reads 8 weights of column c (stride ldw), writes 16 B of each plane at the swizzled chunk
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(idx % C);
+  const long r1 = idx / C;
+  const int ch = (int)(r1 & 3), j = (int)(r1 >> 2);
+  if (j >= ksteps) return;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * j + 8 * ch + e;
+    v[e] = k < K ? w[(long)k * ldw + c] : 0.f;
+  }
+  u32x2 h0, l0, h1, l1;
+  split4(v[0], v[1], v[2], v[3], h0, l0);
+  split4(v[4], v[5], v[6], v[7], h1, l1);
+  const int chs = ch ^ (((c >> 2) & 1) << 1);
+  const long plane = (long)ksteps * C * 64;
+  unsigned char* dst = Wp + ((long)j * C + c) * 64 + chs * 16;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<u32x4*>(dst + plane) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char x1_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wc = wave & 1, wp = wave >> 1;
+  // work item = (pixel tile, column tile), column tile fastest (the workgroups of one pixel tile run side by side: its gradient rows
+  // are fetched from HBM once); XCD x works through a contiguous range of items
+  const unsigned total = gridDim.x, L = blockIdx.x, xq = L & 7u, qq = total >> 3, rr = total & 7u;
+  const unsigned item = xq * qq + (xq < rr ? xq : rr) + (L >> 3);
+  const int mt = (int)(item / (unsigned)p.ctiles), ctile = (int)(item - (unsigned)mt * (unsigned)p.ctiles);
+  const int BM = p.PT * 16, m0 = mt * BM;
+  const int nct = p.ct_n[ctile], ct0 = p.ct_c0[ctile], BN = nct * 16;
+  // this wave: 16-channel tiles [tw0, tw0 + ntw) of the column tile, 16-pixel tiles [pw0, pw0 + npw) of the pixel tile
+  const int ntw_max = (nct + 1) >> 1, tw0 = wc * ntw_max, ntw = min(ntw_max, nct - tw0);
+  const int npw_max = (p.PT + 3) >> 2, pw0 = wp * npw_max, npw = max(0, min(npw_max, p.PT - pw0));
+  const __amdgpu_buffer_rsrc_t srdG = xsrd(p.G, p.g_bytes), srdW = xsrd(p.Wp, p.w_bytes), srdX = xsrd(p.X, p.x_bytes);
+
+  // ---- staging maps.  Gradient: float4 (row = idx >> 3, 4 k at 4 (idx & 7)) -> 8 B of each plane; weights: 16-byte pieces, verbatim ----
+  unsigned g_voff[X1_MTW]; unsigned g_lds[X1_MTW]; int g_k[X1_MTW];
+#pragma unroll
+  for (int u = 0; u < X1_MTW; ++u) {
+    const int idx = tid + 512 * u, row = idx >> 3, f4 = idx & 7;
+    const bool ok = row < BM && m0 + row < p.M;
+    g_k[u] = ok ? 4 * f4 : 0x40000000;
+    g_voff[u] = (unsigned)(m0 + row) * (unsigned)(p.ldg * 4) + (unsigned)(f4 * 16);
+    g_lds[u] = (unsigned)(row * 64 + (((f4 >> 1) ^ (((row >> 2) & 1) << 1)) * 16) + (f4 & 1) * 8);
+  }
+  const int wpieces = BN * 8;                                  // 16-byte pieces of the weight slab: both planes
+  const unsigned w_plane = (unsigned)p.ksteps * (unsigned)p.C * 64u;
+  f32x4 rg[X1_MTW]; u32x4 rw[3];
+  auto load_slab = [&](int j) {
+#pragma unroll
+    for (int u = 0; u < X1_MTW; ++u)
+      rg[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int q = tid + 512 * u, pl = q >= BN * 4, r = pl ? q - BN * 4 : q;      // piece r of plane pl: row r >> 2, chunk r & 3 (already swizzled in memory)
+      rw[u] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(q < wpieces ? (unsigned)pl * w_plane + ((unsigned)j * (unsigned)p.C + (unsigned)(ct0 * 16)) * 64u + (unsigned)r * 16u : XOOB), 0, 0);
+    }
+  };
+  auto store_slab = [&](unsigned char* st) {
+#pragma unroll
+    for (int u = 0; u < X1_MTW; ++u) {
+      if ((tid + 512 * u) >> 3 < BM) {
+        u32x2 hi, lo;
+        split4(rg[u][0], rg[u][1], rg[u][2], rg[u][3], hi, lo);
+        *reinterpret_cast<u32x2*>(st + g_lds[u]) = hi;
+        *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int q = tid + 512 * u, pl = q >= BN * 4, r = pl ? q - BN * 4 : q;
+      if (q < wpieces) *reinterpret_cast<u32x4*>(st + 2 * X1_G_IMG + pl * X1_W_IMG + r * 16) = rw[u];
+    }
+  };
+
+  f32x4 acc[X1_MTW][X1_NTW];
+#pragma unroll
+  for (int i = 0; i < X1_MTW; ++i)
+#pragma unroll
+    for (int t = 0; t < X1_NTW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned fr = (unsigned)(l16 * 64 + ((g ^ (((l16 >> 2) & 1) << 1)) * 16));      // fragment offset inside a 16-row tile of either image
+
+  load_slab(0);
+  store_slab(x1_smem);
+  __syncthreads();
+  for (int j = 0; j < p.ksteps; ++j) {
+    const bool more = j + 1 < p.ksteps;
+    const unsigned char* const st = x1_smem + (j & 1) * X1_STAGE;
+    if (more) load_slab(j + 1);                                // in flight under this slab's MFMAs
+    bf16x8 gh[X1_MTW], gl[X1_MTW];
+#pragma unroll
+    for (int i = 0; i < X1_MTW; ++i)
+      if (i < npw) {
+        gh[i] = *reinterpret_cast<const bf16x8*>(st + (pw0 + i) * 1024 + fr);
+        gl[i] = *reinterpret_cast<const bf16x8*>(st + X1_G_IMG + (pw0 + i) * 1024 + fr);
+      }
+#pragma unroll
+    for (int t = 0; t < X1_NTW; ++t)
+      if (t < ntw) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + (tw0 + t) * 1024 + fr);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + X1_W_IMG + (tw0 + t) * 1024 + fr);
+#pragma unroll
+        for (int i = 0; i < X1_MTW; ++i)
+          if (i < npw) {
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[i], acc[i][t], 0, 0, 0);
+          }
+      }
+    if (more) store_slab(x1_smem + ((j + 1) & 1) * X1_STAGE);   // the other stage: every wave left it at the previous barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: a lane owns channels c4 .. c4 + 3 (D rows 4 g + r) of pixel m (D column l16) ----
+#pragma unroll
+  for (int t = 0; t < X1_NTW; ++t) {
+    if (t >= ntw) continue;
+    const int c4 = (ct0 + tw0 + t) * 16 + 4 * g;
+    const bool cok = c4 < p.C;
+    f32x4 xs = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
+    if (MASK && cok) { xs = *reinterpret_cast<const f32x4*>(p.x_scale + c4); xt = *reinterpret_cast<const f32x4*>(p.x_shift + c4); }
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned vx = (unsigned)(m0 + pw0 * 16 + l16) * (unsigned)(p.ldx * 4) + (unsigned)(c4 * 4);
+    f32x4 xv[X1_MTW];
+    if (MASK) {
+#pragma unroll
+      for (int i = 0; i < X1_MTW; ++i)
+        xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (int)((cok && i < npw && m0 + (pw0 + i) * 16 + l16 < p.M) ? vx : XOOB), i * 16 * p.ldx * 4, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < X1_MTW; ++i) {
+      const int m = m0 + (pw0 + i) * 16 + l16;
+      const bool ok = cok && i < npw && m < p.M;
+      f32x4 v = acc[i][t];
+      if (MASK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(xv[i][e], xs[e], xt[e]) > 0.f ? v[e] : 0.f;
+        if (ok) { s0 += v; s1 += v * xv[i]; }
+      }
+      if (ok) *reinterpret_cast<f32x4*>(p.out + (long)m * p.ldc + c4) = v;       // (plain global stores: see the note in xs_dgrad3x3_kernel)
+    }
+    if (MASK) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = s0[e], b = s1[e];
+        a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+        a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+        a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+        a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+        if (l16 == e) { s0[0] = a; s1[0] = b; }
+      }
+      if (l16 < 4 && cok && npw > 0) {
+        atomicAdd(p.stat0 + c4 + l16, (double)s0[0]);
+        atomicAdd(p.stat1 + c4 + l16, (double)s1[0]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool xs_wgrad1x1_supported(const WgradArgs& a) {
@@ -584,6 +778,62 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   } else {
     RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(xs_dgrad3x3_kernel<false>, grid, dim3(256), lds, s, k);
+  }
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+size_t xs_dgrad1x1_workspace_bytes(int K, int C) { return (size_t)2 * ((K + 31) / 32) * C * 64; }
+
+bool xs_dgrad1x1_supported(const FwdArgs& a) {
+  const ConvGeom& g = a.g;
+  const bool one = g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.PH == 0 && g.PW == 0 && g.H == g.Ho && g.W == g.Wo;
+  return one && a.N % 16 == 0 && a.N >= 16 && a.N <= 4 * X1_BNMAX && a.C % 4 == 0 && a.C >= 32 && a.bias == nullptr && !a.accumulate && !a.add_out;
+}
+
+int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+  RDM_CHECK_ARG(xs_dgrad1x1_supported(a), "split-precision 1x1 dgrad: needs a 1x1 / stride 1 convolution, 16 <= N (%d) <= %d a multiple of 16, C (%d) a multiple of 4", a.N, 4 * X1_BNMAX, a.C);
+  RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 1x1 dgrad: plain or gate + statistics epilogue only");
+  RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
+  RDM_CHECK_ARG(epi != EPI_MASK_STATS || (a.X && a.x_scale && a.x_shift && a.stat0 && a.stat1 && a.ldx % 4 == 0 && ((uintptr_t)a.X & 15) == 0), "split-precision 1x1 dgrad: the gate needs X, scale, shift and both statistics");
+  const int K = a.C, C = a.N, ksteps = (K + 31) / 32;
+  RDM_CHECK_ARG(ws != nullptr && ((uintptr_t)ws & 15) == 0 && ws_bytes >= xs_dgrad1x1_workspace_bytes(K, C), "split-precision 1x1 dgrad: workspace too small or misaligned (%zu < %zu)", ws_bytes, xs_dgrad1x1_workspace_bytes(K, C));
+  const long M = a.M;
+  const long gb = ((M - 1) * a.lda + K) * 4, xb = a.X ? ((M - 1) * a.ldx + C) * 4 : 16;
+  if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 dgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  {
+    const long threads = (long)ksteps * 4 * C;
+    hipLaunchKernelGGL(k_xs_pack_w1_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.ldw, K, C, ksteps, static_cast<unsigned char*>(ws));
+    RDM_LAUNCH_OK();
+  }
+  XsDgrad1Args k{};
+  k.G = a.A; k.ldg = a.lda; k.K = K; k.Wp = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
+  k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
+  k.M = (int)M; k.C = C; k.ksteps = ksteps;
+  // column tiles of <= 12 sixteen-channel tiles, as even as possible
+  const int nct = C / 16, ctiles = (nct + 2 * X1_NTW - 1) / (2 * X1_NTW);
+  int c0 = 0;
+  for (int t = 0; t < ctiles; ++t) { k.ct_c0[t] = c0; k.ct_n[t] = nct / ctiles + (t < nct % ctiles ? 1 : 0); c0 += k.ct_n[t]; }
+  k.ctiles = ctiles;
+  // tile height: one workgroup per CU; the cheapest (rounds of 256 workgroups x tile height) wins
+  int best_pt = 1; long best_cost = -1;
+  for (int pt = 1; pt <= 4 * X1_MTW; ++pt) {
+    const long items = (long)cdiv(M, 16 * pt) * ctiles, rounds = (items + 255) / 256;
+    const long cost = rounds * (pt * 16 + 24);                  // + a fixed per-tile cost (prologue / epilogue) in pixel units
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pt = pt; }
+  }
+  k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
+  k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad1x1_workspace_bytes(K, C); k.x_bytes = (unsigned)xb;
+  void* prof = profile_begin(s, 2.0 * (double)M * C * K, 16);
+  RDM_CENSUS("xs_dgrad1x1_kernel/%s", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  const dim3 grid((unsigned)(k.mtiles * k.ctiles));
+  if (epi == EPI_MASK_STATS) {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS));
+    hipLaunchKernelGGL(xs_dgrad1x1_kernel<true>, grid, dim3(512), X1_LDS, s, k);
+  } else {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS));
+    hipLaunchKernelGGL(xs_dgrad1x1_kernel<false>, grid, dim3(512), X1_LDS, s, k);
   }
   profile_end(prof, s);
   RDM_LAUNCH_OK();

@@ -130,3 +130,48 @@ def test_xs_dgrad3x3_vs_float64(case):
     assert rel(dz.cpu().double(), wantz) < TOL
     assert rel(s0.cpu(), wantz.sum(0)) < 1e-5 and rel(s1.cpu(), (wantz * y.double()).sum(0)) < 1e-5
     _RAN.add(("xs_dgrad3x3", case))
+
+
+DGRAD1_CASES = [
+    # B, H, W, K (= Cb, contracted), N (= cin, outputs), ldx (mask buffer row stride)
+    (4, 57, 76, 2736, 336, 384),     # dense_e2 conv1, last layer (RDM_Net.py:526): two column tiles (11 + 10 sixteen-channel tiles), K = 85.5 steps (ragged)
+    (16, 29, 38, 1392, 192, 768),    # dense_e3 conv1, first layer (RDM_Net.py:528): one column tile, 80-pixel tiles (an idle wave row)
+    (3, 41, 43, 144, 96, 96),        # short K, 6 sixteen-channel tiles (3 + 3), 5 289 pixels: ragged last pixel tile
+    (2, 33, 35, 1392, 720, 768),     # dense_e3's last layer width: 4 column tiles
+]
+
+
+@pytest.mark.parametrize("case", DGRAD1_CASES, ids=[f"d1x1_{i}" for i in range(len(DGRAD1_CASES))])
+def test_xs_dgrad1x1_vs_float64(case):
+    """xs_dgrad1x1_kernel, plain and with the ReLU gate + BatchNorm-backward sums, against a float64 product."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, K, N, ldx = case
+    M = B * H * W
+    g = torch.Generator().manual_seed(6000 + N)
+    gy = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    x = torch.randn(M, ldx, generator=g)
+    sc = torch.rand(N, generator=g) + 0.5
+    sh = torch.randn(N, generator=g) * 0.3
+    want = gy.double() @ w.double()
+    d = ConvDesc(B, H, W, N, N, K, K, 1, 1, 1, 1, 0, 0)
+    gyg, wg, xg, scg, shg = gy.to(dev), w.to(dev), x.to(dev), sc.to(dev), sh.to(dev)
+    wsb = L.rdm_conv1x1_dgrad_x3_workspace_bytes(K, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dx = torch.full((M, N), float("nan"), device=dev)
+    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dx), N, None, 0, None, None, None, None, ptr(ws), wsb, stream()))
+    err = rel(dx.cpu().double(), want)
+    assert err < TOL, err
+    s0 = torch.zeros(N, dtype=torch.float64, device=dev)
+    s1 = torch.zeros_like(s0)
+    dz = torch.full((M, N), float("nan"), device=dev)
+    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dz), N, ptr(xg), ldx, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    xin = x[:, :N]
+    gate = torch.addcmul(sh, xin, sc) > 0
+    wantz = want * gate
+    assert rel(dz.cpu().double(), wantz) < TOL
+    assert rel(s0.cpu(), wantz.sum(0)) < 1e-5 and rel(s1.cpu(), (wantz * xin.double()).sum(0)) < 1e-5
+    _RAN.add(("xs_dgrad1x1", case))

@@ -75,6 +75,35 @@ def dg3(B, H, W, Cb):
           f"| x3 vs f32 kernel {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
 
 
+def dg1(B, H, W, Cb, cin, ld):
+    M = B * H * W
+    X = torch.randn(M, ld, device=dev)
+    dZ = torch.randn(M, Cb, device=dev)
+    w1 = torch.randn(Cb, cin, device=dev) * 0.05
+    sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.3
+    d = ConvDesc(B, H, W, cin, cin, Cb, Cb, 1, 1, 1, 1, 0, 0)
+    dX = torch.empty(M, cin, device=dev)
+    s0 = torch.zeros(cin, dtype=torch.float64, device=dev); s1 = torch.zeros_like(s0)
+    wsb = L.rdm_conv1x1_dgrad_x3_workspace_bytes(Cb, cin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    def f32(): check(L.rdm_conv2d_dgrad(C.byref(d), ptr(dZ), ptr(w1), ptr(dX), cin, ptr(X), ld, ptr(sc), ptr(sh), ptr(s0), ptr(s1), stream()))
+    def x3(): check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(dZ), ptr(w1), ptr(dX), cin, ptr(X), ld, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    outs = {}
+    for k, fn in (("f32", f32), ("x3", x3)):
+        fn(); torch.cuda.synchronize(); outs[k] = dX[:4096].clone()
+    diff = ((outs["x3"] - outs["f32"]).abs().max() / outs["f32"].abs().max()).item()
+    t = timeit({"f32": f32, "x3": x3})
+    fl = 2.0 * M * Cb * cin
+    by = 4.0 * M * (Cb + 2 * cin)
+    print(f"dg1 M={M} K={Cb} N={cin}: f32 {t['f32']*1e3:.3f} ms {fl/t['f32']/1e12:.0f} TF | x3 {t['x3']*1e3:.3f} ms {fl/t['x3']/1e12:.0f} TF-equiv ({by/t['x3']/1e12:.2f} TB/s algorithmic) "
+          f"| x3 vs f32 kernel {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
+
+
+if which in ("dg1", "all"):
+    for cin in (96, 192, 336):
+        dg1(16, 57, 76, 2736, cin, 384)
+    for cin in (192, 480, 720):
+        dg1(16, 29, 38, 1392, cin, 768)
 if which in ("dg3", "all"):
     dg3(16, 57, 76, 2736)
     dg3(16, 29, 38, 1392)
