@@ -131,7 +131,7 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * points above; every float32 operand is split into two bf16 pieces at staging time and each product is formed as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores with float32 accumulation (error ~5e-6 of the result's maximum; the exact-f32
  * MFMA kernels: ~1e-6).  Gradients only - the forward pass never goes through these.  RDM_ERR_UNSUPPORTED for shapes without such a kernel
- * (1x1: 96 <= in_c <= 1536, in_c a multiple of 48). */
+ * (1x1: 96 <= in_c <= 1536, in_c a multiple of 48; 3x3 / stride 1 / pad 1: out_c <= 48, rows of <= 93 pixels). */
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward

@@ -262,6 +262,7 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
   a.split_k = split_k;
   a.xsplit = 1;
   if (d->kh == 1 && d->kw == 1) return launch_xs_wgrad1x1(a, stream);
+  if (d->kh == 3 && d->kw == 3) return launch_xs_wgrad3x3(a, stream);
   set_error("conv2d_wgrad_x3: no split-precision kernel for a %dx%d convolution", d->kh, d->kw);
   return RDM_ERR_UNSUPPORTED;
 }

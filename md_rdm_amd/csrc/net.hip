@@ -580,7 +580,15 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       // packed gradients go straight to the caller's tensor; otherwise into a scratch that is unpacked to OIHW afterwards
       float* dW3 = n.opt_packed3x3 ? F(Gr, L.conv2) : at<float>(ws, W.dw3);
       RDM_HIP_OK(hipStreamWaitEvent(side, n.ev_go, 0));
-      if (n.wino_wg[b] && !n.opt_no_wino) {
+      WgradArgs xw{};
+      xw.g = geom3x3(n.B, g.H, g.W, 1);
+      xw.G = go; xw.ldg = g.ctot; xw.N = GROWTH; xw.Xs = Y; xw.ldx = cb; xw.C = cb; xw.x_scale = bn2; xw.x_shift = bn2 + cb;
+      xw.dW = dW3; xw.wtap = (long)GROWTH * cb; xw.ldw = cb; xw.xsplit = 1;
+      if (n.xs_block(b) && xs_wgrad3x3_supported(xw)) {
+        // split-precision direct kernel: accumulates with f32 atomics into the zeroed gradient
+        if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
+        if ((rc = launch_xs_wgrad3x3(xw, side))) return rc;
+      } else if (n.wino_wg[b] && !n.opt_no_wino) {
         // Winograd F(3x3, 2x2): writes the gradient (ordered split reduction, no atomics, no zero fill)
         WinoWgrad wv{};
         wv.G = go; wv.ldg = g.ctot; wv.N = GROWTH; wv.A = Y; wv.lda = cb; wv.C = cb; wv.a_scale = bn2; wv.a_shift = bn2 + cb;

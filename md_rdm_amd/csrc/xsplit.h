@@ -14,4 +14,7 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
 bool xs_dgrad1x1_supported(const FwdArgs& a);
 size_t xs_dgrad1x1_workspace_bytes(int K, int C);
 int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s);
+// 3x3 / stride 1 / pad 1 weight gradient with <= 48 output channels: operands and meaning of launch_conv_wgrad (dW pre-zeroed, accumulated)
+bool xs_wgrad3x3_supported(const WgradArgs& a);
+int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s);
 }  // namespace rdm

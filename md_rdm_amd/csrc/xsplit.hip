@@ -692,6 +692,195 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
   }
 }
 
+
+// =============================================================================================
+// 3x3 / stride 1 / pad 1 WEIGHT gradient of the dense layers' conv2 (48 output channels):
+//     dW[tap][n][c] += sum_m go[m][n] * f(Y[pix(m, tap)][c]),  pix(m, (r, q)) = (y - 1 + r, x - 1 + q),  f = ReLU(BatchNorm) or identity.
+// The contraction runs over PADDED positions u of the (H + 2) x (W + 2) frame of every image: with zeros at the frame's border in BOTH
+// operands, every tap is a plain shift  u -> u + (r - 1)(W + 2) + (q - 1)  and no product needs a mask (6 - 12 % more k-steps than pixels).
+//  * the activations of the workgroup's 64 channels live in an LDS RING of 256 padded positions ([position][16-channel tile] bf16 images as
+//    in the 1x1 kernel, hi and lo plane): every slab of 32 positions is loaded, normalised, split and stored ONCE and then read by the
+//    nine taps of the seven slabs around it through ds_read_b64_tr_b16 at shifted rows (a lane supplies its own row's address, so the
+//    shifts need no alignment); the 48-channel gradient slab is double-buffered.  ONE barrier per slab.
+//  * a wave owns one 16-channel tile: 9 taps x 3 gradient tiles = 27 accumulator tiles (108 registers), 81 MFMAs per slab.
+//  * K split over the slabs; partial sums leave with f32 atomics into the (pre-zeroed) packed gradient.
+// =============================================================================================
+constexpr int XW_RING = 256, XW_BC = 64, XW_YPLANE = XW_RING * XW_BC * 2, XW_GPLANE = 32 * 48 * 2;      // 32 KB, 3 KB
+constexpr int XW_LDS = 2 * XW_YPLANE + 4 * XW_GPLANE;
+
+struct XsWgrad3Args {
+  const float* G; int ldg;                 // output gradient [M][ldg], 48 channels
+  const float* Y; int ldy; int C;          // forward input (pre BatchNorm) [M][ldy], C channels
+  const float* y_scale; const float* y_shift;
+  float* dW; long wtap; int ldw; int N;    // packed gradient [tap][n][c]
+  int B, H, W;
+  int nslab, split, ahead;                 // slabs of 32 padded positions; K splits; slabs the activation ring runs ahead (= behind): ceil((W + 3) / 32)
+  unsigned g_bytes, y_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[XW_LDS];
+  unsigned char* const Yhi = smem;
+  unsigned char* const Ylo = smem + XW_YPLANE;
+  unsigned char* const Gb = smem + 2 * XW_YPLANE;            // [buffer][hi | lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int grp = tid >> 4, kq = l16 >> 2, jq = l16 & 3;
+  const int Wp = p.W + 2, PP = (p.H + 2) * Wp, U = p.B * PP;
+  const int c0 = blockIdx.x * XW_BC;
+  const int per = (p.nslab + p.split - 1) / p.split;
+  const int s_begin = blockIdx.y * per, s_end = min(p.nslab, s_begin + per);
+  if (s_begin >= s_end) return;
+  const __amdgpu_buffer_rsrc_t srdG = xsrd(p.G, p.g_bytes), srdY = xsrd(p.Y, p.y_bytes);
+  const bool bnrelu = p.y_scale != nullptr;
+
+  // ---- staging maps.  Activations: patch (rg = (grp >> 2) + 4 it, ct = grp & 3): slab row 4 rg + kq, channels c0 + 16 ct + 4 jq .. + 3 ----
+  const int yc = c0 + 16 * (grp & 3) + 4 * jq;
+  const bool ycok = yc < p.C;
+  f32x4 ysc = {1.f, 1.f, 1.f, 1.f}, ysh = {0.f, 0.f, 0.f, 0.f};
+  if (bnrelu && ycok) { ysc = *reinterpret_cast<const f32x4*>(p.y_scale + yc); ysh = *reinterpret_cast<const f32x4*>(p.y_shift + yc); }
+  // offset of (padded position u, this thread's channel quad) or XOOB for a border / out-of-range position
+  // (u < 2^21: floor((u + 0.5) / d) through one float multiply is exact - the quotient's error stays far below the 0.5 / d margin)
+  const float rPP = 1.0f / (float)PP, rWp = 1.0f / (float)Wp;
+  auto pix_off = [&](int u, int ld, int col, bool colok) -> unsigned {
+    const int b = (int)(((float)u + 0.5f) * rPP), rem = u - b * PP, yp = (int)(((float)rem + 0.5f) * rWp), xp = rem - yp * Wp;
+    const bool ok = u >= 0 && u < U && colok && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
+    return ok ? (unsigned)((b * p.H + yp - 1) * p.W + xp - 1) * (unsigned)(ld * 4) + (unsigned)(col * 4) : XOOB;
+  };
+  auto y_lds = [&](int s, int it) -> unsigned {              // ring position of (slab s, this thread's row of patch it)
+    const int row = ((s & 7) << 5) + 4 * ((grp >> 2) + 4 * it) + kq;
+    const int rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
+    return (unsigned)(256 * (rb * 4 + (grp & 3)) + 32 * pr + 8 * jq);
+  };
+  f32x4 ry[2]; float yhi[2];
+  auto load_y = [&](int s) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const unsigned off = pix_off(s * 32 + 4 * ((grp >> 2) + 4 * it) + kq, p.ldy, yc, ycok);
+      ry[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdY, (int)off, 0, 0));
+      yhi[it] = off != XOOB ? __builtin_inff() : 0.f;        // ReLU upper bound: 0 zeroes a border position after BatchNorm
+    }
+  };
+  auto store_y = [&](int s) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      f32x4 v = ry[it];
+      if (bnrelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], ysc[e], ysh[e]), 0.f, yhi[it]);
+      }
+      u32x2 hi, lo;
+      split4(v[0], v[1], v[2], v[3], hi, lo);
+      const unsigned a = y_lds(s, it);
+      *reinterpret_cast<u32x2*>(Yhi + a) = hi;
+      *reinterpret_cast<u32x2*>(Ylo + a) = lo;
+    }
+  };
+  // gradient slab: 24 patches (8 row groups x 3 sixteen-channel tiles): group grp takes patch grp, groups 0..7 also patch 16 + grp
+  f32x4 rgv[2];
+  auto load_g = [&](int s) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
+      const unsigned off = pi < 24 ? pix_off(s * 32 + 4 * rg + kq, p.ldg, 16 * ct + 4 * jq, 16 * ct + 4 * jq < p.N) : XOOB;
+      rgv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)off, 0, 0));
+    }
+  };
+  auto store_g = [&](int s) {
+    unsigned char* const gb = Gb + (s & 1) * (2 * XW_GPLANE);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
+      if (pi < 24) {
+        u32x2 hi, lo;
+        split4(rgv[it][0], rgv[it][1], rgv[it][2], rgv[it][3], hi, lo);
+        const int row = 4 * rg + kq, rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
+        const unsigned a = (unsigned)(256 * (rb * 3 + ct) + 32 * pr + 8 * jq);
+        *reinterpret_cast<u32x2*>(gb + a) = hi;
+        *reinterpret_cast<u32x2*>(gb + XW_GPLANE + a) = lo;
+      }
+    }
+  };
+
+  // ---- fragment addresses.  Gradient (A operand, rows = n): as in the 1x1 kernel.  Activations (B operand, columns = c of this wave's
+  // tile): k group g, half r' reads slab rows 8 g + 4 r' + q shifted by the tap; per tap and half one ring offset (before the slab's base) ----
+  const int fq = l16 >> 2, fp = l16 & 3;
+  const unsigned frG0 = (unsigned)(256 * (g * 3) + 32 * ((fq) ^ ((g & 1) << 2)) + 8 * fp);
+  const unsigned frG1 = (unsigned)(256 * (g * 3) + 32 * ((4 + fq) ^ ((g & 1) << 2)) + 8 * fp);
+  // ring byte offset of (tap, half) for slab 0; a slab further = 4 row blocks = 4096 bytes further (mod the 32 KB plane): the row's low
+  // three bits and its block's parity - all the swizzle depends on - do not change
+  unsigned ybase[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, q = tap - 3 * r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = (8 * g + 4 * h + fq + (r - 1) * Wp + (q - 1)) & (XW_RING - 1);
+      const int rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
+      ybase[tap][h] = (unsigned)(256 * (rb * 4 + wave) + 32 * pr + 8 * fp);
+    }
+  }
+  auto y_frag = [&](const unsigned char* plane, unsigned soff, int tap) -> bf16x8 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(plane + ((ybase[tap][0] + soff) & (unsigned)(XW_YPLANE - 1))));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(plane + ((ybase[tap][1] + soff) & (unsigned)(XW_YPLANE - 1))));
+    const s16x8 ab = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    return __builtin_bit_cast(bf16x8, ab);
+#else
+    return bf16x8{};
+#endif
+  };
+
+  f32x4 acc[9][3];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) acc[tap][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: activation slabs s_begin - ahead .. s_begin + ahead, gradient slab s_begin ----
+  for (int s = s_begin - p.ahead; s <= s_begin + p.ahead; ++s) { load_y(s); store_y(s); }
+  load_g(s_begin);
+  store_g(s_begin);
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool more = s + 1 < s_end;
+    if (more) { load_y(s + 1 + p.ahead); load_g(s + 1); }     // in flight under this slab's MFMAs
+    const unsigned char* const gb = Gb + (s & 1) * (2 * XW_GPLANE);
+    bf16x8 ah[3], al[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      ah[nt] = tr_frag(gb + frG0, gb + frG1, 256 * nt);
+      al[nt] = tr_frag(gb + XW_GPLANE + frG0, gb + XW_GPLANE + frG1, 256 * nt);
+    }
+    const unsigned soff = ((unsigned)s * 4096u) & (unsigned)(XW_YPLANE - 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const bf16x8 bh = y_frag(Yhi, soff, tap), bl = y_frag(Ylo, soff, tap);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[tap][nt], 0, 0, 0);
+        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[tap][nt], 0, 0, 0);
+        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh, acc[tap][nt], 0, 0, 0);
+      }
+    }
+    if (more) { store_y(s + 1 + p.ahead); store_g(s + 1); }   // ring slot (s + 1 + ahead) & 7 and gradient buffer (s + 1) & 1: last read one slab ago
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = 4 g + r (n), column = l16 (c): f32 atomics into the packed gradient ----
+  const int c = c0 + 16 * wave + l16;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + 4 * g + r;
+        if (c < p.C && n < p.N) atomicAdd(p.dW + (long)tap * p.wtap + (long)n * p.ldw + c, acc[tap][nt][r]);
+      }
+}
+
 }  // namespace
 
 bool xs_wgrad1x1_supported(const WgradArgs& a) {
@@ -835,6 +1024,43 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
     RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS));
     hipLaunchKernelGGL(xs_dgrad1x1_kernel<false>, grid, dim3(512), X1_LDS, s, k);
   }
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+bool xs_wgrad3x3_supported(const WgradArgs& a) {
+  const ConvGeom& g = a.g;
+  return g.KH == 3 && g.KW == 3 && g.SH == 1 && g.SW == 1 && g.PH == 1 && g.PW == 1 && g.H == g.Ho && g.W == g.Wo && g.dir == 1 && a.N <= 48 && a.N % 4 == 0 &&
+         a.C % 4 == 0 && a.C >= 16 && (g.W + 3 + 31) / 32 <= 3;
+}
+
+int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
+  RDM_CHECK_ARG(xs_wgrad3x3_supported(a), "split-precision 3x3 wgrad: needs a 3x3 / stride 1 / pad 1 convolution with N (%d) <= 48, N and C (%d) multiples of 4, W (%d) <= 93", a.N, a.C, a.g.W);
+  RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "split-precision 3x3 wgrad: strides multiples of 4 floats, operands 16-byte aligned");
+  const long M = (long)a.g.B * a.g.H * a.g.W;
+  const long gb = ((M - 1) * a.ldg + a.N) * 4, yb = ((M - 1) * a.ldx + a.C) * 4;
+  if (gb >= 0xFFFFFFFFL || yb >= 0xFFFFFFFFL) { set_error("split-precision 3x3 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  XsWgrad3Args k{};
+  k.G = a.G; k.ldg = a.ldg; k.Y = a.Xs; k.ldy = a.ldx; k.C = a.C; k.y_scale = a.x_scale; k.y_shift = a.x_shift;
+  k.dW = a.dW; k.wtap = a.wtap; k.ldw = a.ldw; k.N = a.N; k.B = a.g.B; k.H = a.g.H; k.W = a.g.W;
+  const long U = (long)a.g.B * (a.g.H + 2) * (a.g.W + 2);
+  k.nslab = (int)((U + 31) / 32);
+  k.ahead = (a.g.W + 3 + 31) / 32;
+  const int cblocks = cdiv(a.C, XW_BC);
+  // K split: (column blocks x splits) fill the 512 workgroup slots in whole rounds; every split pays 2 * ahead + 1 slabs of prologue
+  int best = 1; double best_cost = 1e30;
+  const int max_split = a.split_k > 0 ? a.split_k : 64;
+  for (int sp = a.split_k > 0 ? a.split_k : 1; sp <= max_split && sp <= std::max(1, k.nslab / 8); ++sp) {
+    const long rounds = ((long)cblocks * sp + 511) / 512;
+    const double cost = rounds * ((k.nslab + sp - 1) / sp + 2.0 * k.ahead + 3.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+  }
+  k.split = best;
+  k.g_bytes = (unsigned)gb; k.y_bytes = (unsigned)yb;
+  void* prof = profile_begin(s, 2.0 * (double)M * a.N * 9.0 * a.C, 15);
+  RDM_CENSUS("xs_wgrad3x3_kernel/%s", a.x_scale ? "bn1" : "bn0");
+  hipLaunchKernelGGL(xs_wgrad3x3_kernel, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;

@@ -175,3 +175,49 @@ def test_xs_dgrad1x1_vs_float64(case):
     assert rel(dz.cpu().double(), wantz) < TOL
     assert rel(s0.cpu(), wantz.sum(0)) < 1e-5 and rel(s1.cpu(), (wantz * xin.double()).sum(0)) < 1e-5
     _RAN.add(("xs_dgrad1x1", case))
+
+
+def _ref3x3_wgrad(gy, a):
+    import torch.nn.functional as F
+    B, H, W, N = gy.shape
+    Cc = a.shape[3]
+    ap = F.pad(a, (0, 0, 1, 1, 1, 1))
+    g2 = gy.reshape(-1, N).t().contiguous()
+    return torch.stack([g2 @ ap[:, r:r + H, q:q + W, :].reshape(-1, Cc) for r in range(3) for q in range(3)])
+
+
+WGRAD3_CASES = [
+    # B, H, W, C, ld, N, ldg, bn
+    (4, 57, 76, 336, 336, 48, 384, True),        # dense_e2's map (RDM_Net.py:526): ring runs 3 slabs ahead; 5 full column blocks + a 16-wide one
+    (16, 29, 38, 1392, 1392, 48, 96, True),      # dense_e3 conv2 at the bench batch (RDM_Net.py:528): 21 full blocks + 48 channels; ring 2 slabs ahead
+    (3, 20, 93, 80, 96, 40, 40, False),          # widest supported rows, no prologue, N < 48, ld > C
+    (2, 9, 7, 64, 64, 48, 48, True),             # tiny frame: many border positions per slab
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_CASES, ids=[f"w3x3_{i}" for i in range(len(WGRAD3_CASES))])
+def test_xs_wgrad3x3_vs_float64(case):
+    """xs_wgrad3x3_kernel (padded-frame contraction, LDS ring, transposed reads at shifted rows) against shifted-slice float64 products: image
+    borders, batch boundaries, ragged channel blocks, the launcher's K split and split_k = 1 / 3."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cc, ld, N, ldg, bn = case
+    g = torch.Generator().manual_seed(7000 + Cc)
+    x = torch.randn(B, H, W, ld, generator=g)
+    x[..., Cc:] = float("nan")
+    gyb = torch.randn(B, H, W, ldg, generator=g)
+    gy = gyb[..., :N].contiguous()
+    sc = torch.rand(Cc, generator=g) + 0.5
+    sh = torch.randn(Cc, generator=g) * 0.3
+    a = (torch.relu(x[..., :Cc] * sc + sh) if bn else x[..., :Cc]).double()
+    want = _ref3x3_wgrad(gy.double(), a)
+    d = ConvDesc(B, H, W, Cc, ld, N, ldg, 3, 3, 1, 1, 1, 1)
+    xg, gyg, scg, shg = x.to(dev), gyb.to(dev), sc.to(dev), sh.to(dev)
+    for split in (0, 1, 3):
+        dw = torch.zeros(9, N, Cc, device=dev)
+        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, stream()))
+        err = rel(dw.cpu().double(), want)
+        assert err < TOL, (split, err)
+    _RAN.add(("xs_wgrad3x3", case))

@@ -99,6 +99,31 @@ def dg1(B, H, W, Cb, cin, ld):
           f"| x3 vs f32 kernel {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
 
 
+def wg3(B, H, W, Cb):
+    M = B * H * W
+    Y = torch.randn(M, Cb, device=dev)
+    sc = torch.rand(Cb, device=dev) + 0.5; sh = torch.randn(Cb, device=dev) * 0.3
+    g48 = torch.randn(M, 48, device=dev)
+    d3 = ConvDesc(B, H, W, Cb, Cb, 48, 48, 3, 3, 1, 1, 1, 1)
+    dW = torch.zeros(9, 48, Cb, device=dev)
+    wsb = L.rdm_conv3x3_wino_wgrad_workspace_bytes(Cb, B, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    def f32(): check(L.rdm_conv3x3_wino_wgrad(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), ptr(ws), wsb, stream()))
+    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), 0, stream()))
+    outs = {}
+    for k, fn in (("f32", f32), ("x3", x3)):
+        dW.zero_(); fn(); torch.cuda.synchronize(); outs[k] = dW.clone()
+    diff = ((outs["x3"] - outs["f32"]).abs().max() / outs["f32"].abs().max()).item()
+    t = timeit({"f32": f32, "x3": x3})
+    fl = 2.0 * M * Cb * 432
+    by = 4.0 * M * (Cb + 48)
+    print(f"wg3 M={M} Cb={Cb}: winograd f32 {t['f32']*1e3:.3f} ms {fl/t['f32']/1e12:.0f} TF | x3 {t['x3']*1e3:.3f} ms {fl/t['x3']/1e12:.0f} TF-equiv ({by/t['x3']/1e12:.2f} TB/s algorithmic) "
+          f"| x3 vs winograd f32 {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
+
+
+if which in ("wg3", "all"):
+    wg3(16, 57, 76, 2736)
+    wg3(16, 29, 38, 1392)
 if which in ("dg1", "all"):
     for cin in (96, 192, 336):
         dg1(16, 57, 76, 2736, cin, 384)
