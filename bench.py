@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# Multi-process GPU work on this ROCm stack (RCCL, tensors shared across ranks) needs dmabuf IPC: the host driver does not support the legacy
+# IPC mode and hipIpcGetMemHandle fails with "invalid argument" without this.  It must be in the environment BEFORE the first HIP call of the
+# process (the driver's launcher exports it as well; setdefault keeps an explicit choice of the caller).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -70,7 +75,8 @@ def main():
         a3.steps, a3.warmup = min(args.steps, 5), min(args.warmup, 2)
         e = bench_train(a3, 8, 352, 1216, with_cpu_baseline=False, metric="depth-maps/sec KITTI 352x1216 batch=8 fwd+bwd")
         extra.append({k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")})
-        out["extra_configs"] = extra
+        # nested under `config`: the driver's record keeps nested keys of the line, not new top-level ones
+        out["config"]["extra_configs"] = extra
     if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -195,16 +201,31 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         L.rdm_profile_enable(0)
         h = model._plan(B, H, W)[0]
         algo = (L.rdm_net_forward_flops(h) + L.rdm_net_backward_flops(h)) * args.steps   # reference-algorithmic conv FLOPs
-        peak = 157.3                                            # fp32 MFMA peak, MI355X_MICROARCH.md
+        PEAK_F32, PEAK_BF16 = 157.3, 2500.0                     # dense MFMA peaks (TFLOP/s), MI355X_MICROARCH.md: f32-in/f32-acc, bf16
+        peak = PEAK_F32
         achieved = algo / (ms.value * 1e-3) / 1e12
-        per_kernel = []
+        # what each kernel family EXECUTES on the matrix pipe per algorithmic FLOP: the Winograd kernels (kinds 9, 10) multiply 1 / 2.25 as
+        # much on the f32 pipe; the split-precision kernels (13-16) run three bf16 MFMAs per product on the bf16 pipe
+        def pipe_of(kind):
+            return ("bf16", 3.0, PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
+        per_kernel, busy_ms = [], 0.0
+        executed_f32 = executed_bf16 = 0.0
         for kind in list(range(11)) + [13, 14, 15, 16]:
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:
+                pipe, mult, ppeak = pipe_of(kind)
+                sec = kms.value * 1e-3
+                ex = kfl.value * mult
+                if pipe == "f32":
+                    executed_f32 += ex
+                else:
+                    executed_bf16 += ex
+                busy_ms += ex / (ppeak * 1e12) * 1e3             # time the pipe needs for these FLOPs at its peak
                 per_kernel.append({"kernel": nm.value.decode(), "launches_per_step": kn.value // max(args.steps, 1),
                                    "avg_launch_us": round(kms.value / kn.value * 1e3, 1), "ms_sum_per_step": round(kms.value / args.steps, 3),
-                                   "tflops": round(kfl.value / (kms.value * 1e-3) / 1e12, 1), "frac": round(kfl.value / (kms.value * 1e-3) / 1e12 / peak, 3)})
+                                   "tflops": round(kfl.value / sec / 1e12, 1), "pipe": pipe, "executed_tflops": round(ex / sec / 1e12, 1),
+                                   "pipe_peak": ppeak, "frac": round(ex / sec / 1e12 / ppeak, 3)})
         per_kernel.sort(key=lambda r: -r["ms_sum_per_step"])
         # `roofline` follows the contract literally: the DOMINANT kernel (largest summed duration) with algorithmic FLOPs per launch /
         # its average launch duration measured live (HIP events on its launch stream; NB it runs on the side stream BESIDE the dgrad
@@ -224,18 +245,45 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
             traffic_src = ("profiles/" + os.path.basename(tpath) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled per the gfx950 "
                            "correction, checked on k_adamw), bytes per launch of this kernel averaged over one step")
         step_frac = algo / args.steps / (elapsed / args.steps) / 1e12 / peak
-        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["executed_tflops"], "peak": dom["pipe_peak"], "unit": "TFLOP/s", "frac": dom["frac"],
+                "algorithmic_tflops": dom["tflops"], "pipe": dom["pipe"],
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
-                "note": "dominant kernel by summed duration; it overlaps the dgrad chain on the side stream (isolated: DESIGN.md 4.1)",
-                "conv_family": {"kernel": "all fp32 MFMA implicit-GEMM conv kernels", "achieved": round(achieved, 2), "frac": round(achieved / peak, 4),
+                "note": "dominant kernel by summed duration; achieved = FLOPs it executes on its matrix pipe / its average launch duration (for a direct f32 kernel = the algorithmic FLOPs)",
+                "conv_family": {"kernel": "all MFMA conv kernels (f32, Winograd f32, bf16x3 split)", "achieved": round(achieved, 2), "frac": round(achieved / peak, 4),
                                 "basis": "algorithmic conv FLOPs of the step / union of the conv kernels' intervals", "traffic_per_launch": fam_traffic,
                                 "launches_per_step": n.value // max(args.steps, 1), "kernel_ms_per_step": round(ms.value / args.steps, 3),
                                 "kernel_ms_sum_per_step": round(ms_sum.value / args.steps, 3)},
-                "whole_step": {"achieved": round(step_frac * peak, 2), "frac": round(step_frac, 4), "basis": "algorithmic conv FLOPs / ms_per_step (driver-timed formula)"},
+                "whole_step": {"achieved": round(step_frac * peak, 2), "frac": round(step_frac, 4), "basis": "algorithmic conv FLOPs / ms_per_step over the f32 MFMA peak (driver-timed formula; > the pipe-busy fraction because Winograd and the bf16x3 kernels execute fewer / cheaper FLOPs than the algorithm counts)"},
                 "per_kernel": per_kernel, "library_launches_per_step_all_kernels": round(lib_launches_per_step, 1),
                 "timing": "HIP events on the launch streams over K further steps run right after the timed region",
-                "executed_tflop_per_step": round(fl.value / args.steps / 1e12, 4), "algorithmic_tflop_per_step": round(algo / args.steps / 1e12, 4)}
+                "algorithmic_tflop_per_step": round(algo / args.steps / 1e12, 4),
+                "executed_f32_tflop_per_step": round(executed_f32 / args.steps / 1e12, 4), "executed_bf16_tflop_per_step": round(executed_bf16 / args.steps / 1e12, 4),
+                # fraction of the step during which the matrix pipes would be busy if every MFMA ran at its pipe's peak rate
+                "mfma_busy_frac": round(busy_ms / args.steps / (elapsed / args.steps * 1e3), 4)}
 
+    # communication figures of the line (config.comm): what the exchange moves, how much of it the backward pass did not hide, what the
+    # per-stage ordering of the weight-gradient stream costs - measured over a few further steps, outside the timed region
+    comm = {"allreduce_bytes_per_step": sync.bytes_per_step() if world > 1 else 0, "stages": len(sync.slices),
+            "exchange": "one asynchronous RCCL all-reduce (sum) per backward stage on the flat gradient buffer, last layers first; AdamW applies 1/N"}
+    if world > 1:
+        sync.timing = True
+        for _ in range(min(args.steps, 3)):
+            step()
+        comm["exposed_wait_ms_per_step"] = round(sync.exposed_ms() or 0.0, 3)
+        comm["exposed_wait_basis"] = "device events around GradSync.finish(): compute stream idle until the last reduction has landed"
+        comm["side_stream_join"] = "after every backward stage (the exchange consumes gradients stage by stage)"
+        sync.timing = False
+    elif not args.no_roofline:
+        # N = 1: the cost of joining the weight-gradient stream after each of the 13 stages (what N > 1 pays) instead of once per segment
+        hook = model.grad_ready_hook
+        model.grad_ready_hook = (lambda stage: None) if hook is None or world == 1 else hook
+        torch.cuda.synchronize()
+        tj = time.perf_counter()
+        for _ in range(min(args.steps, 5)):
+            step()
+        torch.cuda.synchronize()
+        comm["per_stage_join_overhead_ms"] = round((time.perf_counter() - tj) / min(args.steps, 5) * 1e3 - elapsed / args.steps * 1e3, 3)
+        model.grad_ready_hook = hook
     note(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     cpu = None
     if rank == 0 and world == 1 and with_cpu_baseline:
@@ -247,9 +295,13 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         ms_step = elapsed / args.steps * 1e3
         out = {"metric": metric, "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.backward_precision == "f32" else "f32 (bf16x3-split gradient GEMMs)", "data": "synthetic",
                "config": {"workload": f"{'KITTI' if (H, W) == (352, 1216) else 'NYU-v2'} {H}x{W} batch={B}/GPU full train step (fwd+losses+bwd+AdamW), DepthEstimationNet 90.5M params",
-                          "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss.item())},
+                          "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
+                          "precision": ("forward, losses, BatchNorm, AdamW: float32 (exact-f32 MFMA); weight / input gradient GEMMs of dense_e2 and dense_e3: float32 operands split "
+                                        "into bf16 hi + lo, three bf16 MFMAs per product, float32 accumulation (~5e-6 of a gradient's maximum vs ~1e-6 for the f32 kernels); "
+                                        "--backward-precision f32 runs every GEMM on the f32 pipe") if args.backward_precision != "f32" else "float32 everywhere (exact-f32 MFMA)",
+                          "comm": comm},
                "roofline": roof, "cpu_baseline": cpu}
     return out
 
@@ -390,8 +442,11 @@ def cpu_baseline(H, W, batch=16, warmup=1, iters=2):
     """the oracle's FULL train step (PyTorch-CPU restatement of the reference: forward + losses + backward
     + torch.optim.AdamW over the 491 parameter tensors) at the headline batch of 16, float32, BatchNorm in train mode, on the GPU
     box's host cores.  The plan's "3 warm-up + 5 timed" would be ~2.5 minutes of CPU at ~15 s per step; bounded here to 1 warm-up
-    + 2 timed steps (~45 s) so the default bench run stays within minutes - the sample says so."""
+    + 2 timed steps (~45 s) so the default bench run stays within minutes - the sample says so.  RDM_CPU_BASELINE_FULL=1 runs the
+    BASELINE.md-conformant 3 + 5 (profiles/ keeps one such sample per round)."""
     import numpy as np
+    if os.environ.get("RDM_CPU_BASELINE_FULL", "0") not in ("", "0"):
+        warmup, iters = 3, 5
     from md_rdm_amd import filler
     from oracle import rdm_net_cpu as onet
     n, how = host_threads()                                             # every core the box really gives this process
@@ -427,7 +482,7 @@ def cpu_baseline(H, W, batch=16, warmup=1, iters=2):
         pass
     out = {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model,
            "sample": f"median of {iters} full train steps (fwd + losses + bwd + AdamW) at batch {batch}, {H}x{W}, fp32, BatchNorm train mode, after {warmup} warm-up "
-                     f"(BASELINE.md 3 asks 3 + 5; bounded to keep the bench run within minutes); {dt:.1f} s per step; "
+                     f"(BASELINE.md 3 asks 3 + 5: RDM_CPU_BASELINE_FULL=1; the default is bounded to keep the bench run within minutes); {dt:.1f} s per step; "
                      f"threads = {n}: {how}"}
     out["input_pipeline"] = input_pipeline_baseline(H, W)
     return out

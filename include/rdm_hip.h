@@ -48,24 +48,19 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..12 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-6 the direct f32 MFMA kernels,
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..16 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-5 the direct f32 MFMA kernels, 13-16 the split-precision bf16x3 gradient kernels - FLOPs = the float32 product's, i.e. algorithmic,
  * 7-8 and 11-12 the bf16 forward kernels, 9-10 the Winograd f32 forward / weight-gradient kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for the f32 kinds) */
 double rdm_profile_kind_bytes(int32_t kind);
-/* development switch for in-process A/B timing of the measured alternatives DESIGN.md 4.1 cites (0 = shipped):
- * 7 generic instead of halo 3x3, 8 no forward pipelining, 9 generic instead of row wgrad, 11 hardware block order,
- * 13 128x96 wgrad tiles only, 14 default-priority side stream, 16/20 256x48 tiles on 1x1 convs, 21 256-pixel halo tiles only,
- * 23 full-size wgrad tiles at small M, 26 hand-pipelined (251-VGPR) row wgrad.  Results never depend on it beyond float rounding.
- * It exists only in libraries built with RDM_DEV_VARIANTS=1; the shipped build compiles the alternatives out (the switch is a
- * compile-time 0, no launcher reads mutable global state) and this call reports an error for v != 0. */
-void rdm_debug_variant(int32_t v);
+/* (The development A/B switch of earlier rounds is NOT part of this ABI: it is declared in include/rdm_dev.h and exists only in libraries
+ * built with RDM_DEV_VARIANTS=1; the shipped library does not export it.) */
 /* number of kernel-launching calls the library has made in this process (monotonic; bench.py reports the per-step difference;
  * a K-split launcher that also enqueues its zero-fill or reduction counts once per enqueued kernel family) */
 int64_t rdm_launch_count(void);
 
 /* Launch census (test instrumentation): while enabled, every MFMA conv launcher records which kernel VARIANT it picked - e.g.
- * "conv3x3_halo_kernel/dgrad/px256/hl6/MASK_STATS", "conv_wgrad3_row_kernel/48x256x3/splitK", "conv1x1_dma256_kernel/STORE_STATS/bn1" -
+ * "conv3x3_halo_kernel/dgrad/px256/hl6/MASK_STATS", "xs_dgrad3x3_kernel/MASK_STATS", "conv1x1_dma256_kernel/STORE_STATS/bn1" -
  * so tests/test_gpu_conv.py can assert that the variants the headline geometry (B=16, 228x304) selects are the ones its parity cases
  * ran.  rdm_census_count() snapshots the table and returns its size; rdm_census_entry(i) reads entry i of that snapshot (the name
  * stays valid until the next rdm_census_count()). */
@@ -277,9 +272,11 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                and 78 unpack launches + 78 scratch fills per backward.
  *   RDM_NET_OPT_GRADS_PREZEROED  the caller guarantees that every gradient tensor is all zero when backward stage 0 starts (one fill
  *                                of a flat gradient buffer instead of ~160 per-tensor fills inside the plan).
- *   RDM_NET_OPT_DIRECT_3X3       every 3x3 convolution on the direct implicit-GEMM kernels (default 0: the blocks with >= 16 384 pixels -
- *                                dense_e2 / dense_e3 at the headline geometry - run Winograd F(2x2, 3x3), csrc/wino.hip; same result to
- *                                float32 rounding, tests/test_gpu_wino.py).
+ *   RDM_NET_OPT_DIRECT_3X3       every exact-f32 3x3 convolution on the direct implicit-GEMM kernels (default 0: blocks with >= 8 192 pixels run
+ *                                the Winograd F(2x2, 3x3) forward, blocks with >= 12 288 pixels the Winograd F(3x3, 2x2) weight gradient -
+ *                                dense_e2 / dense_e3 at the headline geometry; csrc/wino.hip; same result to float32 rounding,
+ *                                tests/test_gpu_wino.py).  With RDM_NET_OPT_SPLIT_BWD the weight gradient of those blocks runs the
+ *                                split-precision kernel instead and this option then only concerns the forward.
  *   RDM_NET_OPT_DETERMINISTIC    ordered reductions everywhere (for tests): no K split (so no f32 atomics with more than one contributor),
  *                                channel statistics and the dgrad gate / BatchNorm-backward sums as separate passes with a fixed summation
  *                                order, no layer pipelining.  Two runs on the same inputs then give bit-identical gradients; several
@@ -341,8 +338,10 @@ int rdm_net_buffer(const rdm_net* net, const char* name, int64_t* offset_bytes, 
 double rdm_net_forward_flops(const rdm_net* net);
 double rdm_net_backward_flops(const rdm_net* net);
 
-/* Layout changes at the edges of the NHWC conv stack (the reference's tensors are NCHW: RDM_Net.py:70-135): src (B,C,HW) -> dst (B,HW,dst_ld)
- * channel prefix, and back.  Used by the relative decoders d_6..d_10, which enter the stack with the encoder output. */
+/* Layout changes at the edges of the NHWC conv stack (the reference's tensors are NCHW: RDM_Net.py:70-135): src (B,C,HW) -> dst (B,HW,dst_ld) and
+ * back.  nchw_to_nhwc writes EVERY element of every dst row: channels [0, C) from src, channels [C, dst_ld) as zeros - do not aim it at a slice
+ * of a wider buffer whose other channels must survive (convert into a scratch of ld = C for that).  nhwc_to_nchw reads the channel prefix
+ * [0, C) of rows of stride src_ld.  Used by the relative decoders d_6..d_10, which enter the stack with the encoder output. */
 int rdm_layout_nchw_to_nhwc_f32(const float* src, float* dst, int32_t dst_ld, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream);
 int rdm_layout_nhwc_to_nchw_f32(const float* src, int32_t src_ld, float* dst, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream);
 
@@ -356,8 +355,13 @@ int rdm_dorn_bwd(const float* logits, const double* dord, float* dlogits, int32_
 /* loss (1 float, pre-zeroed) = -(sum_{k<=t} log P + sum_{k>t} log(1-P)) / (B*HW), float32 logs */
 int rdm_ordinal_loss_fwd(const double* ord, const int32_t* target, float* loss, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
 int rdm_ordinal_loss_bwd(const double* ord, const int32_t* target, const float* dloss, double* dord, int32_t batch, int32_t k, int32_t hw, rdm_stream_t stream);
-/* utils.py:195-211 depth2label_sid on float64 depth: int32 labels */
-int rdm_depth2label_sid(const double* depth, int32_t* label, int64_t n, rdm_stream_t stream);
+/* utils.py:195-211 depth2label_sid on float64 depth: int32 labels.  A non-positive depth (a bicubic-resized target overshoots below zero next
+ * to an invalid pixel) gives NaN before the reference's `.int()`, whose result depends on the DEVICE the reference ran on:
+ *   RDM_SID_NAN_CPU   0x80000000 (x86 "integer indefinite") - what the parity fixtures, generated on the CPU, pin; the default
+ *   RDM_SID_NAN_CUDA  0 - what the reference's production path (is_cuda = True, utils.py:205-211) computes on its GPU */
+typedef enum rdm_sid_nan { RDM_SID_NAN_CPU = 0, RDM_SID_NAN_CUDA = 1 } rdm_sid_nan;
+int rdm_depth2label_sid(const double* depth, int32_t* label, int64_t n, rdm_stream_t stream);      /* = _ex(..., RDM_SID_NAN_CPU, ...) */
+int rdm_depth2label_sid_ex(const double* depth, int32_t* label, int64_t n, int32_t nan_semantics, rdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * network/computations.py post-processing (float64 unless noted)

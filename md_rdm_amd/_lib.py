@@ -23,7 +23,6 @@ _SIGNATURES = {
     "rdm_last_error_string": (C.c_char_p, []),
     "rdm_version": (C.c_int, []),
     "rdm_profile_enable": (None, [i32]),
-    "rdm_debug_variant": (None, [i32]),
     "rdm_launch_count": (i64, []),
     "rdm_census_enable": (None, [i32]),
     "rdm_census_reset": (None, []),
@@ -98,6 +97,7 @@ _SIGNATURES = {
     "rdm_ordinal_loss_fwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "rdm_ordinal_loss_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "rdm_depth2label_sid": (C.c_int, [vp, vp, i64, vp]),
+    "rdm_depth2label_sid_ex": (C.c_int, [vp, vp, i64, i32, vp]),
     "rdm_resize_bicubic_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "rdm_gm_normalize_f64": (C.c_int, [vp, vp, vp, i32, i32, f64, vp]),
     "rdm_decompose_f64": (C.c_int, [vp, vp, i32, i32, vp]),
@@ -148,6 +148,16 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)     # AttributeError here = header/library drift: fail loudly
             fn.restype, fn.argtypes = res, args
+        # development A/B switch (include/rdm_dev.h): exported by RDM_DEV_VARIANTS=1 builds only; on the shipped library the tools' calls
+        # land in a Python stub that accepts 0 (= the shipped configuration) and refuses anything else
+        try:
+            dv = getattr(L, "rdm_debug_variant")
+            dv.restype, dv.argtypes = None, [i32]
+        except AttributeError:
+            def _no_variants(v):
+                if int(v) != 0:
+                    raise RdmError(f"rdm_debug_variant({int(v)}): this library was built without RDM_DEV_VARIANTS - rebuild with RDM_DEV_VARIANTS=1 python -m md_rdm_amd.build")
+            L.rdm_debug_variant = _no_variants
         _lib = L
     return _lib
 

@@ -98,22 +98,23 @@ def _allowed_globals():
         allowed[("numpy", "dtype")] = np.dtype
         for name in ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool_"):
             allowed[("numpy", name)] = getattr(np, name)
-    except ImportError:
+    except (ImportError, AttributeError):            # a numpy without this layout of np._core / np.core: skip the numpy entries, do not abort the load
         pass
     return allowed
+
+
+_ALLOWED_GLOBALS = None          # built once per process (torch.load wraps the Unpickler in a fresh subclass per call: a cache on type(self) is thrown away)
 
 
 class _TensorOnlyUnpickler(pickle.Unpickler):
     """Resolves ONLY the exact globals of _allowed_globals(); every other global a file names (pytorch_lightning classes, argparse
     Namespaces - or builtins.eval, os.system, anything a hostile file puts into a __reduce__) becomes the inert stand-in, whose
     construction and state restoration do nothing."""
-    _ALLOWED = None
-
     def find_class(self, module, name):
-        cls = type(self)
-        if cls._ALLOWED is None:
-            cls._ALLOWED = _allowed_globals()
-        return cls._ALLOWED.get((module, name), _Inert)
+        global _ALLOWED_GLOBALS
+        if _ALLOWED_GLOBALS is None:
+            _ALLOWED_GLOBALS = _allowed_globals()
+        return _ALLOWED_GLOBALS.get((module, name), _Inert)
 
 
 class _TensorOnlyPickle:

@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "rdm_common.h"
+#ifdef RDM_DEV_VARIANTS
+#include "../../include/rdm_dev.h"
+#endif
 #include "elementwise.h"
 #include "bf16.h"
 #include "wino.h"
@@ -59,16 +62,9 @@ extern "C" {
 const char* rdm_last_error_string(void) { return g_err; }
 int rdm_version(void) { return 100; }
 
-void rdm_debug_variant(int32_t v) {
 #ifdef RDM_DEV_VARIANTS
-  rdm::g_variant = v;
-#else
-  if (v != 0) {
-    rdm::set_error("rdm_debug_variant(%d): this library was built without RDM_DEV_VARIANTS - the shipped configuration is the only one", (int)v);
-    fprintf(stderr, "[librdm_hip] rdm_debug_variant(%d) ignored: built without RDM_DEV_VARIANTS\n", (int)v);
-  }
+void rdm_debug_variant(int32_t v) { rdm::g_variant = v; }      // include/rdm_dev.h: development builds only
 #endif
-}
 int64_t rdm_launch_count(void) { return rdm::g_launches; }
 void rdm_census_enable(int32_t on) { rdm::g_census_on = on != 0; }
 void rdm_census_reset(void) {
@@ -311,6 +307,7 @@ int rdm_conv3x3_wino_wgrad(const rdm_conv_desc* d, const float* dy, const float*
   RDM_CHECK_ARG(dy && x && dw && workspace, "conv3x3_wino_wgrad: NULL operand");
   RDM_CHECK_ARG(d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1, "conv3x3_wino_wgrad: 3x3 / stride 1 / pad 1 only");
   RDM_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "conv3x3_wino_wgrad: bn_scale and bn_shift go together");
+  RDM_CHECK_ARG(d->out_c >= 4 && d->out_c <= 48 && d->out_c % 4 == 0 && d->in_c >= 4 && d->in_c % 4 == 0, "conv3x3_wino_wgrad: out_c (%d) must be 4 .. 48 and, like in_c (%d), a multiple of 4", d->out_c, d->in_c);
   RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "conv3x3_wino_wgrad: workspace must be 256-byte aligned");
   if (workspace_bytes < rdm_conv3x3_wino_wgrad_workspace_bytes(d->in_c, d->batch, d->in_h, d->in_w)) {
     set_error("conv3x3_wino_wgrad: workspace too small: %zu < %zu", workspace_bytes, rdm_conv3x3_wino_wgrad_workspace_bytes(d->in_c, d->batch, d->in_h, d->in_w));

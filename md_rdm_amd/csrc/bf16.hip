@@ -1066,8 +1066,9 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
   const bool panel = !out_f32 && !a.bias && split == 1 && a.K <= 352 && a.M >= 8192 && a.N >= 1024 && (long)cdiv(a.M, 256) * cdiv(a.N, 96) >= 1024;
   void* tk = profile_begin(s, 2.0 * a.M * a.N * (double)a.K, panel ? 11 : 7, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (double)a.M * a.N * (out_f32 ? 4 : 2));
   if (panel) {
-    static int n_cu = 0;
-    if (!n_cu) { hipDeviceProp_t pr; int dev = 0; RDM_HIP_OK(hipGetDevice(&dev)); RDM_HIP_OK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
+    // per call, for the CURRENT device (a process may drive several GPUs, from several threads): the attribute query is a cached host-side lookup
+    int n_cu = 0;
+    { int dev = 0; RDM_HIP_OK(hipGetDevice(&dev)); RDM_HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)); }
     const int nkk = cdiv(a.K, 32), nks = (nkk + 1) / 2, lds = 2 * nks * PANEL_STEP + 4 * PANEL_EPI + nkk * 256;
     const long ob = ((long)(a.M - 1) * a.ldc + a.N) * 2;
     if (ob >= 0xFFFFFFFFL) { set_error("gemm_bf16: output extent >= 4 GiB"); return RDM_ERR_UNSUPPORTED; }
@@ -1075,8 +1076,8 @@ int launch_gemm_bf16(const GemmBf16Args& a_in, bool out_f32, hipStream_t s) {
     dim3 grid((unsigned)n_cu);
 #define RDM_GP(NKK_)                                                                                                                      \
   case NKK_: {                                                                                                                             \
-    static bool attr_set = false;                                                                                                          \
-    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_bf16_kernel<NKK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((NKK_ + 1) / 2) * PANEL_STEP + 4 * PANEL_EPI + NKK_ * 256)); attr_set = true; } \
+    /* set on every launch: the attribute is per device and per function, the call is a cheap host-side store */                          \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_bf16_kernel<NKK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((NKK_ + 1) / 2) * PANEL_STEP + 4 * PANEL_EPI + NKK_ * 256)); \
     hipLaunchKernelGGL((gemm_panel_bf16_kernel<NKK_>), grid, dim3(512), lds, s, a);                                                        \
   } break
     switch (nkk) { RDM_GP(1); RDM_GP(2); RDM_GP(3); RDM_GP(4); RDM_GP(5); RDM_GP(6); RDM_GP(7); RDM_GP(8); RDM_GP(9); RDM_GP(10); RDM_GP(11); default: break; }
@@ -1243,8 +1244,7 @@ int launch_conv3x3_act_bf16(const Conv3ActArgs& a_in, hipStream_t s) {
   dim3 grid((unsigned)(a.B * pl.tpi), (unsigned)pl.split);
 #define RDM_C3A(NC_)                                                                                                                      \
   case NC_: {                                                                                                                              \
-    static bool attr_set = false;                                                                                                          \
-    if (!attr_set) { RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_act_bf16_kernel<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, ACT_LDS_BYTES)); attr_set = true; } \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_act_bf16_kernel<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, ACT_LDS_BYTES)); /* per device: set on every launch */ \
     hipLaunchKernelGGL((conv3x3_act_bf16_kernel<NC_>), grid, dim3(NC_ * 128), ACT_LDS_BYTES, s, a);                                        \
   } break
   switch (pl.nc) {

@@ -96,15 +96,18 @@ __global__ void k_ordinal_loss_bwd(const double* __restrict__ P, const int* __re
 
 // utils.py:195-211 with the reference's dtype quirks: alpha = float32(0.02), K = float32(90),
 // log(beta/alpha) evaluated in float32 (= 0x1.8dbc24p+2); tensor arithmetic in float64.
-__global__ void k_depth2label_sid(const double* __restrict__ d, int* __restrict__ label, long n) {
+// nan_label: the label of a non-positive depth (NaN after the log) - the reference's `.int()` of NaN is device dependent
+__global__ void k_depth2label_sid(const double* __restrict__ d, int* __restrict__ label, long n, int nan_label) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double alpha = 0x1.47ae14p-6, den = 0x1.8dbc24p+2;
   double l = 90.0 * log(d[i] / alpha) / den;
   // d <= 0 happens (a bicubic-resized target overshoots below zero next to an invalid pixel): log gives NaN, torch.max PROPAGATES it
   // (C fmax would not) and the reference's `.int()` of NaN on the CPU - the machine the parity fixtures were generated on - is x86's
-  // "integer indefinite" 0x80000000.  The ordinal loss then sees a label below every index (all 90 pairs on the `k > t` side).
-  label[i] = (l != l) ? (int)0x80000000 : (int)fmax(l, 0.0);
+  // "integer indefinite" 0x80000000 (RDM_SID_NAN_CPU, the default: pinned by the fixtures).  The ordinal loss then sees a label below every
+  // index (all 90 pairs on the `k > t` side).  On CUDA - where the reference trains, utils.py:205-211 with cuda=True - the same cast gives 0
+  // (RDM_SID_NAN_CUDA).
+  label[i] = (l != l) ? nan_label : (int)fmax(l, 0.0);
 }
 
 }  // namespace rdm
@@ -148,9 +151,14 @@ int rdm_ordinal_loss_bwd(const double* ord, const int32_t* target, const float* 
 }
 
 int rdm_depth2label_sid(const double* depth, int32_t* label, int64_t n, rdm_stream_t stream) {
+  return rdm_depth2label_sid_ex(depth, label, n, RDM_SID_NAN_CPU, stream);
+}
+
+int rdm_depth2label_sid_ex(const double* depth, int32_t* label, int64_t n, int32_t nan_semantics, rdm_stream_t stream) {
   RDM_CHECK_ARG(depth && label && n >= 0, "depth2label_sid: bad argument");
+  RDM_CHECK_ARG(nan_semantics == RDM_SID_NAN_CPU || nan_semantics == RDM_SID_NAN_CUDA, "depth2label_sid: nan_semantics (%d) must be RDM_SID_NAN_CPU or RDM_SID_NAN_CUDA", (int)nan_semantics);
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(k_depth2label_sid, dim3(cdiv(n, 256)), dim3(256), 0, stream, depth, label, (long)n);
+  hipLaunchKernelGGL(k_depth2label_sid, dim3(cdiv(n, 256)), dim3(256), 0, stream, depth, label, (long)n, nan_semantics == RDM_SID_NAN_CPU ? (int)0x80000000 : 0);
   RDM_LAUNCH_OK();
   return RDM_OK;
 }

@@ -768,205 +768,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// wgrad of a 3x3 / stride 1 / pad 1 conv: one block owns a whole kernel ROW (3 taps) of a 48 x 256
-// weight tile.  The three taps of a row contract the same gradient pixels against activation
-// pixels that are ONE pixel apart, so the activation slab is staged once (18 pixel rows serve
-// 3 x 16) instead of three times, and its BN-ReLU is applied once.  The activation pixels live in
-// a 48-row LDS ring (3 chunks of 16): slab t reads ring rows 16t .. 16t+17 while chunk t+2 lands.
-// Zero padding is applied on the (small) gradient operand instead of the activations: a per-pixel
-// 3-bit mask (tap q's shifted pixel inside the image?) is staged next to the gradient slab and ANDed
-// into the A fragments - so the activation ring can hold whatever linear neighbour is in memory.
-// LDS strides are 16 mod 32 floats: the four k-groups of a fragment read hit disjoint bank halves
-// (SQ_LDS_BANK_CONFLICT = 0; the generic kernel spends 38 % of its LDS cycles in conflicts).
-// 144 accumulator VGPRs per wave -> 2 waves/SIMD at 219 VGPRs (BN scale/shift kept in LDS to stay under 224: two such waves
-// leave one 64-VGPR wave slot per SIMD to the kernels of the dependent chain).  PIPE = fragment fetch software-pipelined by
-// hand (251 VGPRs).  Measured on the dense_e2 conv2 (M 69312, C 2736, N 48): 1.61 ms (PIPE 1.52) vs 1.74 ms generic.
-// ---------------------------------------------------------------------------------------------
-template <bool PIPE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad3_row_kernel(WgradArgs p) {
-  constexpr int WAVES = 4;
-  constexpr int MT = 3, NT = 16 / WAVES;              // wave tile 48 (n) x 64 (c), times 3 taps
-  constexpr int XL = 16 / WAVES;                      // activation float4 loads per thread and chunk
-  constexpr int BM = 48, BN = 256, LDA = BM, LDB = BN + 16, RING = 48;
-  __shared__ __attribute__((aligned(16))) float Gs[2][BK * LDA];
-  __shared__ unsigned Ms[2][BK];                      // per gradient pixel: bit q set <=> tap q's shifted pixel is inside the image
-  __shared__ __attribute__((aligned(16))) float Xr[RING * LDB];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l16 = lane & 15, g = lane >> 4;
-  const int wcol = wave * NT * 16;
-  const ConvGeom& G = p.g;
-  // the three kernel rows of a work item sit 8 block-ids apart (same XCD, adjacent in time: they read
-  // the same activations shifted by +-W pixels)
-  const long Lb = blockIdx.x, lane8 = Lb & 7, seq = Lb >> 3;
-  const int r = (int)(seq % 3);
-  const long item = lane8 + 8 * (seq / 3);
-  if (item >= p.n_items) return;
-  const int ctiles = (p.C + BN - 1) / BN, ntiles = (p.N + BM - 1) / BM;
-  const int ct = (int)(item % ctiles);
-  const long t2 = item / ctiles;
-  const int nt = (int)(t2 % ntiles), split = (int)(t2 / ntiles);
-  const int c0 = ct * BN, n0 = nt * BM;
-  const int Mpix = G.B * G.H * G.W;
-  const int nslab_total = (Mpix + BK - 1) / BK;
-  const int per = (nslab_total + p.split_k - 1) / p.split_k;
-  const int s_begin = split * per, s_end = min(nslab_total, s_begin + per);
-  if (s_begin >= s_end) return;
-  const int nsl = s_end - s_begin;
-  const int dy = r - 1;
-  const __amdgpu_buffer_rsrc_t srdG = make_srd(p.G, p.g_bytes), srdX = make_srd(p.Xs, p.x_bytes);
-
-  // activation chunk loads: thread -> pixel rows (tid >> 6) + WAVES * i of the chunk, float4 column tid & 63
-  const int xk = tid >> 6, xr4 = tid & 63;
-  const bool xcol_ok = c0 + xr4 * 4 < p.C;
-  const unsigned xcol = (unsigned)((c0 + xr4 * 4) * 4);
-  const bool bnrelu = p.x_scale != nullptr;
-  // the thread's BN scale / shift live in LDS, not in 8 VGPRs: 144 accumulators + fragments already fill the register budget
-  __shared__ __attribute__((aligned(16))) float Ssc[BN], Ssh[BN];
-  if (tid < BN / 4) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bnrelu && c0 + tid * 4 < p.C) { sc = ld4(p.x_scale + c0 + tid * 4); sh = ld4(p.x_shift + c0 + tid * 4); }
-    *reinterpret_cast<float4*>(&Ssc[tid * 4]) = sc;
-    *reinterpret_cast<float4*>(&Ssh[tid * 4]) = sh;
-  }
-  __syncthreads();
-  int xpix = s_begin * BK + dy * G.W - 1 + xk;          // linear input pixel of this thread's first row of chunk 0
-  float4 rx[XL];
-  auto load_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      const int j = xpix + WAVES * i;
-      const bool ok = xcol_ok & (j >= 0) & (j < Mpix);
-      rx[i] = bld4(srdX, ok ? (unsigned)j * (unsigned)(p.ldx * 4) + xcol : OOB);
-    }
-    xpix += BK;
-  };
-  auto store_chunk = [&](int slot) {                     // slot = chunk index mod 3
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      float4 v = rx[i];
-      if (bnrelu) v = bnrelu4(v, *reinterpret_cast<const float4*>(&Ssc[xr4 * 4]), *reinterpret_cast<const float4*>(&Ssh[xr4 * 4]));
-      *reinterpret_cast<float4*>(&Xr[(slot * 16 + xk + WAVES * i) * LDB + xr4 * 4]) = v;
-    }
-  };
-  // gradient slab loads: threads 0..191 -> pixel tid / 12, float4 column tid % 12
-  const bool gthr = tid < BK * (BM / 4);
-  const int gk = tid / (BM / 4), gn4 = tid - gk * (BM / 4);
-  const bool gcol_ok = gthr && n0 + gn4 * 4 < p.N;
-  int gm = s_begin * BK + gk;
-  unsigned gvoff = (unsigned)gm * (unsigned)(p.ldg * 4) + (unsigned)((n0 + gn4 * 4) * 4);
-  int gy, gx;
-  {
-    const int hw = G.H * G.W, rem = gm % hw;
-    gy = rem / G.W; gx = rem - gy * G.W;
-  }
-  float4 rg;
-  unsigned gmask;
-  const int gdx = BK % G.W, gdy = BK / G.W;              // cursor step of one slab
-  auto load_g = [&]() {
-    const bool ok = gcol_ok & (gm < Mpix);
-    rg = bld4(srdG, ok ? gvoff : OOB);
-    const bool row_ok = (unsigned)(gy + dy) < (unsigned)G.H;
-    gmask = row_ok ? (gx >= 1 ? 1u : 0u) | 2u | (gx + 1 < G.W ? 4u : 0u) : 0u;
-    gm += BK; gvoff += (unsigned)(BK * p.ldg * 4);
-    gx += gdx; gy += gdy;
-    if (gx >= G.W) { gx -= G.W; ++gy; }
-    gy %= G.H;
-  };
-  auto store_g = [&](int buf) {
-    if (gthr) {
-      *reinterpret_cast<float4*>(&Gs[buf][gk * LDA + gn4 * 4]) = rg;
-      if (gn4 == 0) Ms[buf][gk] = gmask;
-    }
-  };
-
-  f32x4 acc[3][MT][NT];
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  load_chunk(); store_chunk(0);
-  load_chunk(); store_chunk(1);
-  load_g(); store_g(0);
-  __syncthreads();
-  int buf = 0, slot = 0;                                // slot = t mod 3
-  for (int t = 0; t < nsl; ++t) {
-    const bool more = t + 1 < nsl;
-    if (more) { load_chunk(); load_g(); }
-    const int rb = slot * 16;
-    // fragments of k-step ks+1 are fetched under the MFMAs of k-step ks (explicit two-deep register pipeline;
-    // left alone, the scheduler sinks every ds_read next to its first use and the MFMA pipe waits on LDS)
-    float fa[2][3][MT], fb[2][3][NT];
-    auto fetch = [&](int ks, float (&a)[3][MT], float (&b)[3][NT]) {
-      const int k = ks * 4 + g;
-      const unsigned mk = Ms[buf][k];
-      float araw[MT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) araw[i] = Gs[buf][k * LDA + i * 16 + l16];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const unsigned mq = 0u - ((mk >> q) & 1u);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[q][i] = __uint_as_float(__float_as_uint(araw[i]) & mq);
-        int row = rb + k + q;
-        if (row >= RING) row -= RING;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b[q][j] = Xr[row * LDB + wcol + j * 16 + l16];
-      }
-    };
-    if (PIPE) {
-      fetch(0, fa[0], fb[0]);
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        if (ks + 1 < BK / 4) fetch(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][q][i], fb[ks & 1][q][j], acc[q][i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {                                  // 224 VGPRs: leaves one 64-VGPR wave slot per SIMD to the dependent chain's kernels
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        fetch(ks, fa[0], fb[0]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q][i], fb[0][q][j], acc[q][i][j], 0, 0, 0);
-      }
-    }
-    if (more) { store_chunk(slot == 0 ? 2 : slot - 1); store_g(buf ^ 1); }   // chunk t+2 -> slot (t+2) mod 3
-    __syncthreads();
-    buf ^= 1;
-    slot = slot == 2 ? 0 : slot + 1;
-  }
-
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    float* base = p.dW + (long)(r * 3 + q) * p.wtap;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int c = c0 + wcol + j * 16 + l16;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int n = n0 + i * 16 + g * 4 + rr;
-          if (c < p.C && n < p.N) atomicAdd(base + (long)n * p.ldw + c, acc[q][i][j][rr]);
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // optional per-launch timing of the MFMA kernels (bench.py roofline): HIP events recorded on the
 // launch stream around every conv kernel; read back (and summed) by rdm_profile_read().
 // ---------------------------------------------------------------------------------------------
@@ -990,7 +791,7 @@ struct ProfScope {
 constexpr int PROF_KINDS = 17;
 const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
-    "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "conv_wgrad3_row_kernel",
+    "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "(unused since round 4: the 3x3 row weight-gradient kernel was deleted)",
     "gemm_bf16_kernel (1x1 forward, bf16 MFMA)", "conv3x3_bf16_kernel (3x3 forward, bf16 MFMA)",
     "conv3x3_wino_fwd_kernel (Winograd F(2x2,3x3) forward; FLOPs = the direct convolution's)",
     "conv3x3_wino_wgrad_kernel (Winograd F(3x3,2x2) weight gradient; FLOPs = the direct convolution's)",
@@ -1294,23 +1095,6 @@ static void launch_wgrad_cfg(const WgradArgs& a, bool taps, hipStream_t s) {
   else hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(256), 0, s, b);
 }
 
-// Split-K of the row kernel.  Its 1-D grid deals blocks round-robin over the 8 XCDs in groups of
-// (8 items x 3 kernel rows); an XCD keeps 32 CUs x 2 blocks resident.  A split that fills the CHIP
-// for R rounds can still leave one XCD with R rounds + 1 block (a 50 % tail at R = 2), so the
-// rounds are counted per XCD and the cheapest (rounds x slabs per block) wins.
-static int pick_split_row3(long tiles0, long kslabs) {
-  const long cap = 32 * 2, max_split = std::max(1L, kslabs / 16), overhead = 8;   // overhead: prologue + atomic epilogue, in slab units
-  long best = 1, best_cost = -1;
-  for (long R = 1; R <= 4; ++R) {
-    long split = std::min(max_split, (R * cap / 3) * 8 / tiles0);
-    if (split < 1) split = 1;
-    const long groups = (tiles0 * split + 7) / 8, rounds = (3 * groups + cap - 1) / cap;
-    const long cost = rounds * ((kslabs + split - 1) / split + overhead);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = split; }
-  }
-  return (int)best;
-}
-
 int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   WgradArgs a = a_in;
   if (t_deterministic) a.split_k = 1;                     // one workgroup per output element: its atomic add onto the zeroed gradient is exact
@@ -1333,11 +1117,10 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const bool few = Mpix <= 8192 && g_variant != 23;
   const long tiles = few ? (narrow ? (long)cdiv(a.C, 128) * cdiv(a.N, 48) : (long)cdiv(a.C, 48) * cdiv(a.N, 128)) * ntaps :
                      narrow ? (long)cdiv(a.C, 256) * cdiv(a.N, 48) * ntaps : tall ? (long)cdiv(a.C, 48) * cdiv(a.N, 256) * ntaps : (long)cdiv(a.C, 96) * cdiv(a.N, 128) * ntaps;
-  // 3x3 / stride 1 / pad 1 with few output channels: the row kernel (3 taps per block)
-  const bool row3 = g_variant != 9 && kslabs >= 1024 && a.N <= 96 &&   // long K only: at M <= 4560 the generic kernel's finer tiles win (A/B)
-                    a.g.KH == 3 && a.g.KW == 3 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 1 &&
-                    a.g.PW == 1 && a.g.H == a.g.Ho && a.g.W == a.g.Wo && a.g.dir == 1;
-  if (a.split_k <= 0) a.split_k = row3 ? pick_split_row3((long)cdiv(a.C, 256) * cdiv(a.N, 48), kslabs) : pick_split_k(tiles, kslabs, 256 * 3);
+  // (rounds 1-3 had a dedicated 3x3 "row" kernel for >= 16 K pixels here - one kernel row of taps per block; the plan's many-pixel blocks moved to
+  // Winograd in round 3 and to the split-precision kernel of xsplit.hip in round 4, and the row kernel was deleted: the generic tap kernel
+  // serves the operator API and RDM_NET_OPT_DIRECT_3X3 at every size)
+  if (a.split_k <= 0) a.split_k = pick_split_k(tiles, kslabs, 256 * 3);
   {
     const long gb = ((Mpix - 1) * a.ldg + a.N) * 4, xb = (((long)a.g.B * a.g.H * a.g.W - 1) * a.ldx + a.C) * 4;
     if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
@@ -1345,17 +1128,10 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   }
   a.xcd_flat = g_variant == 11;
   ProfScope prof(s, 2.0 * (double)Mpix * a.N * a.C * ntaps);
-  prof.kind = row3 ? 6 : taps ? 5 : 4;
-  RDM_CENSUS("%s/%s/%s", row3 ? "conv_wgrad3_row_kernel" : taps ? "conv_wgrad_kernel/taps" : "conv_wgrad_kernel/1x1",
-             row3 ? "48x256x3" : few && !narrow ? "128x48" : few ? "48x128" : narrow ? "48x256" : tall ? "256x48" : "128x96", a.split_k > 1 ? "splitK" : "split1");
-  if (row3) {
-    a.n_items = (long)cdiv(a.C, 256) * cdiv(a.N, 48) * a.split_k;
-    const long padded = (a.n_items + 7) / 8 * 8;
-    // shipped: the 219-VGPR build.  The hand-pipelined one (251 VGPRs) is 6 % faster alone (1.52 vs 1.61 ms) but fills the register
-    // file, so nothing of the dependent chain can run beside it: 199.7 vs 204.7 images/s over the whole step (in-process A/B)
-    if (g_variant == 26) hipLaunchKernelGGL(conv_wgrad3_row_kernel<true>, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad3_row_kernel<false>, dim3((unsigned)(padded * 3)), dim3(256), 0, s, a);
-  } else if (few && !narrow) launch_wgrad_cfg<2, 3, 4, 1>(a, taps, s);   // 128 x 48
+  prof.kind = taps ? 5 : 4;
+  RDM_CENSUS("%s/%s/%s", taps ? "conv_wgrad_kernel/taps" : "conv_wgrad_kernel/1x1",
+             few && !narrow ? "128x48" : few ? "48x128" : narrow ? "48x256" : tall ? "256x48" : "128x96", a.split_k > 1 ? "splitK" : "split1");
+  if (few && !narrow) launch_wgrad_cfg<2, 3, 4, 1>(a, taps, s);   // 128 x 48
   else if (few) launch_wgrad_cfg<3, 2, 1, 4>(a, taps, s);                //  48 x 128
   else if (narrow) launch_wgrad_cfg<3, 4, 1, 4>(a, taps, s);   //  48 x 256
   else if (tall) launch_wgrad_cfg<4, 3, 4, 1>(a, taps, s);  // 256 x 48: input-channel counts are multiples of 48, not of 96

@@ -715,6 +715,9 @@ size_t wino_wgrad_part_floats(int B, int H, int W, int C) {
 int launch_conv3x3_wino_wgrad(const WinoWgrad& a, hipStream_t s) {
   RDM_CHECK_ARG(a.N >= 1 && a.N <= 48 && a.N % 4 == 0 && a.C >= 4 && a.C % 4 == 0, "winograd 3x3 wgrad: N (%d) <= 48, N and C (%d) multiples of 4", a.N, a.C);
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldg % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.G & 15) == 0, "winograd 3x3 wgrad: strides multiples of 4 floats, tensors 16-byte aligned");
+  // every argument is validated BEFORE the first launch: a rejected call leaves no work in flight and no scratch half-written
+  RDM_CHECK_ARG(a.dW != nullptr && a.ldw % 4 == 0 && a.wtap % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "winograd 3x3 wgrad: the packed gradient must be 16-byte aligned with strides that are multiples of 4");
+  RDM_CHECK_ARG(a.Vy != nullptr && a.part != nullptr, "winograd 3x3 wgrad: scratch is NULL");
   const long M = (long)a.B * a.H * a.W;
   const long ab = ((M - 1) * a.lda + a.C) * 4, gb = ((M - 1) * a.ldg + a.N) * 4;
   if (ab >= 0xFFFFFFFFL || gb >= 0xFFFFFFFFL) { set_error("winograd 3x3 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
@@ -734,7 +737,6 @@ int launch_conv3x3_wino_wgrad(const WinoWgrad& a, hipStream_t s) {
   else hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel<false>, grid, dim3(512), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
-  RDM_CHECK_ARG(a.ldw % 4 == 0 && a.wtap % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "winograd 3x3 wgrad: the packed gradient must be 16-byte aligned with strides that are multiples of 4");
   hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)cdiv((long)48 * cblocks * 16, 256)), dim3(256), 0, s, a.part, split, cblocks * 64, a.N, a.C, a.dW, a.wtap, a.ldw);
   RDM_LAUNCH_OK();
   return 0;

@@ -32,6 +32,22 @@ class GradSync:
         self.on_buffers_changed = on_buffers_changed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles = []
+        self.timing = False          # True: finish() brackets its waits with a device event pair (bench.py: exposed communication time)
+        self._events = []
+
+    def bytes_per_step(self):
+        """Payload of one step's exchange: the float32 gradient slices of all stages + the small extra tensors."""
+        return 4 * (sum(b - a for a, b in self.slices) + sum(t.numel() for t in self.extra))
+
+    def exposed_ms(self):
+        """Mean device time between the point where the compute stream reaches finish() and the completion of every reduction (the
+        communication the backward pass did NOT hide), over the steps run with ``timing`` on; None if there were none."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        self._events.clear()
+        return sum(ms) / len(ms)
 
     @property
     def flat(self):
@@ -100,6 +116,10 @@ class GradSync:
         the optimiser applies 1/world (``grad_scale``), saving a pass over the buffer."""
         if self.world == 1:
             return 1.0
+        ev = None
+        if self.timing and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         small = [t.grad for t in self.extra if t.grad is not None]
         if small:
             buf = torch.cat([g.reshape(-1) for g in small])
@@ -111,6 +131,9 @@ class GradSync:
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
         return 1.0 / self.world
 
 
@@ -128,7 +151,8 @@ def attach(model, group=None, broadcast_buffers=True):
                     buffers=lambda: list(model.buffers()), flat_buffers=lambda: getattr(model, "_flat_buffers", None),
                     on_buffers_changed=getattr(model, "mark_weights_changed", None))
     model.direct_grads = True
-    model.grad_ready_hook = sync.on_stage
+    # one process: no exchange, so no per-stage consumer - the plan then joins its weight-gradient stream once per segment, not per stage
+    model.grad_ready_hook = sync.on_stage if sync.world > 1 else None
     if broadcast_buffers and sync.world > 1:
         def _pre(module, args):
             if module.training:

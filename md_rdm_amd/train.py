@@ -14,6 +14,10 @@ import sys
 import time
 from argparse import ArgumentParser
 
+# multi-process GPU work on this ROCm stack (RCCL, --gpus N) needs dmabuf IPC - hipIpcGetMemHandle fails with "invalid argument" in the
+# legacy mode; must be in the environment before the first HIP call of the process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 

@@ -27,7 +27,7 @@ def test_two_rank_train_step_matches_single_process_with_averaged_gradients(tmp_
     assert torch.cuda.is_available()
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     port = str(29600 + os.getpid() % 1500)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")      # the child ranks (tests/dp_child.py) share the card: dmabuf IPC, as bench.py / train.py set for themselves
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_child.py"), str(r), "2", port, str(tmp_path), backend],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
@@ -104,7 +104,8 @@ def test_bench_two_ranks_prints_one_weak_scaling_json_line():
     import json
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     port = str(31200 + os.getpid() % 1500)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)          # bench.py sets the dmabuf IPC mode itself (first lines of the file), before any HIP call
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--backend", backend]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -115,5 +116,10 @@ def test_bench_two_ranks_prints_one_weak_scaling_json_line():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]      # images of BOTH ranks / the slowest rank's time
-    assert d["cpu_baseline"] is None and "extra_configs" not in d
+    assert d["cpu_baseline"] is None and "extra_configs" not in d and "extra_configs" not in d["config"]
     assert d["roofline"]["bound"] == "mfma" and np.isfinite(d["config"]["loss"])
+    # the line explains its own communication: payload of the 13-stage exchange (every conv-stack gradient once + the 4 scalars) and the
+    # part of it the backward pass did not hide
+    comm = d["config"]["comm"]
+    assert comm["stages"] == 13 and 350e6 < comm["allreduce_bytes_per_step"] < 380e6
+    assert comm["exposed_wait_ms_per_step"] >= 0.0 and "side_stream_join" in comm

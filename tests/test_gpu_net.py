@@ -285,7 +285,7 @@ def test_fused_adamw_leaves_frozen_encoder_bit_identical(dev):
 
 def test_train_step_b16_228x304_vs_oracle(dev):
     """The BENCH geometry itself (BASELINE configs[2]: B=16, 228x304, full train step) against the CPU oracle on the same seeded
-    batch - the step that selects conv_wgrad3_row_kernel, the 256-pixel halo tiles and conv1x1_dma256_kernel.  Forward: block taps
+    batch - the step that selects the split-precision gradient kernels of dense_e2 / e3, the 256-pixel halo tiles and conv1x1_dma256_kernel.  Forward: block taps
     rtol 1e-4, logits 2e-4 of their max, probabilities 2e-4, losses 1e-4, ordinal indices equal wherever the oracle's decision has
     the +-2.5e-4 margin (this input was not margin-searched; the unsafe pairs are counted and bounded).  Backward: the per-tensor
     criterion of the B=2 test - relative L2 error against the float64 oracle <= 2 x that tensor's own float32-oracle error + 1.5e-2,
@@ -314,8 +314,18 @@ def test_train_step_b16_228x304_vs_oracle(dev):
     assert np.abs(dec - r32["decode"]).max() <= int((~safe).sum(1).max())      # a count can only differ by its unsafe pairs
     np.testing.assert_array_equal(parts["ord_y"].cpu().numpy(), r32["ord_y"])
     got = np.array([parts["mse"].item(), parts["fine_detail_loss"].item(), parts["ord_loss"].item(), loss.item()])
-    if np.array_equal(dec, r32["decode"]):                                      # the mse / fine-detail terms are functions of the integer counts
+    same_counts = np.array_equal(dec, r32["decode"])
+    unsafe_px = int(((~safe).sum(1) > 0).sum())
+    diff_px = int((dec != r32["decode"]).sum())
+    print(f"[b16 oracle] ordinal count maps {'IDENTICAL' if same_counts else 'differ at %d pixels' % diff_px} ({unsafe_px} pixels hold an unsafe pair): "
+          f"the mse / fine-detail / weight_layer comparisons run at {'1e-4' if same_counts else 'the count-perturbation bound'}")
+    assert diff_px <= unsafe_px, (diff_px, unsafe_px)                            # a count may only move where one of its pairs is unsafe
+    if same_counts:                                                             # the mse / fine-detail terms are functions of the integer counts
         np.testing.assert_allclose(got, [r32["mse"], r32["fine_detail_loss"], r32["ord_loss"], r32["loss_all"]], rtol=1e-4)
+    else:
+        # a count that moved by one at `diff_px` of the B*h*w pixels moves the two count-driven terms by at most that fraction of their scale
+        frac = diff_px / dec.size
+        np.testing.assert_allclose(got[:2], [r32["mse"], r32["fine_detail_loss"]], rtol=max(5.0 * frac, 1e-4))
     np.testing.assert_allclose(got[2], r32["ord_loss"], rtol=1e-4)
     sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in onet.new_state_dict(filler.state_value).items()}
     r64 = onet.training_step(sd64, torch.from_numpy(x).double(), y)
@@ -328,7 +338,8 @@ def test_train_step_b16_228x304_vs_oracle(dev):
         if g64 is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0, n
             continue
-        if n.startswith("weight_layer.") and not np.array_equal(dec, r32["decode"]):
+        if n.startswith("weight_layer.") and not same_counts:
+            print(f"[b16 oracle] {n}: gradient comparison skipped (count maps differ, see above)")
             continue                                                            # the 4 scalars see the counts, not the logits
         g, g32 = p.grad.cpu().double(), r32["grads"][n].double()
         n64 = g64.norm().item() + 1e-300

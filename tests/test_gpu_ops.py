@@ -123,6 +123,35 @@ def test_sid_labels_bit_exact(env, op_gold):
     np.testing.assert_array_equal(env["utils"].depth2label_sid(g(big, env)).cpu().numpy(), ocp.depth2label_sid(big))
 
 
+def test_sid_label_of_a_non_positive_depth_is_a_stated_option(env):
+    """depth <= 0 (a bicubic overshoot next to an invalid pixel) -> log -> NaN -> `.int()`: 0x80000000 on the x86 CPU that generated the fixtures
+    (utils.NAN_LABEL = "cpu", default), 0 on the reference's GPU path (NAN_LABEL = "cuda").  Through harness.compute_final_depth either
+    label makes the sample's geometric-mean normalisation non-finite (log of a negative number / of zero), as in the reference; the other
+    samples of the batch are untouched."""
+    from md_rdm_amd import harness
+    utils = env["utils"]
+    dep = np.full((2, 1, 8, 8), 2.0)
+    dep[0, 0, 3, 4] = -0.25
+    dep[0, 0, 0, 0] = 0.0
+    try:
+        utils.NAN_LABEL = "cpu"
+        lab = utils.depth2label_sid(g(dep, env), cuda=True).cpu().numpy()
+        assert lab[0, 0, 3, 4] == np.iinfo(np.int32).min and lab[0, 0, 0, 0] == 0 and lab[1].min() == lab[1].max() == 66      # log(0) = -inf -> max(., 0) = 0
+        utils.NAN_LABEL = "cuda"
+        lab = utils.depth2label_sid(g(dep, env), cuda=True).cpu().numpy()
+        assert lab[0, 0, 3, 4] == 0 and lab[0, 0, 0, 0] == 0 and lab[1].min() == 66
+        for mode in ("cpu", "cuda"):
+            utils.NAN_LABEL = mode
+            target = torch.full((2, 1, 128, 128), 2.0, dtype=torch.float64, device=env["dev"])
+            target[0, 0, 40:56, 40:56] = -0.25                       # an 8x8-resized block of it stays negative
+            fine = [torch.zeros(2, 1, 2 ** i, 2 ** i, device=env["dev"]) for i in range(4)]
+            final, _ = harness.compute_final_depth(fine, target, True)
+            f = final.cpu().numpy()
+            assert not np.isfinite(f[0]).all() and np.isfinite(f[1]).all(), mode
+    finally:
+        utils.NAN_LABEL = "cpu"
+
+
 def test_dorn_head_and_backward(env, op_gold):
     xl = U("op.dorn", (2, 180, 8, 10), -2.0, 3.0)
     xl.flat[::53] = 2e4
