@@ -126,8 +126,8 @@ def test_sid_labels_bit_exact(env, op_gold):
 def test_sid_label_of_a_non_positive_depth_is_a_stated_option(env):
     """depth <= 0 (a bicubic overshoot next to an invalid pixel) -> log -> NaN -> `.int()`: 0x80000000 on the x86 CPU that generated the fixtures
     (utils.NAN_LABEL = "cpu", default), 0 on the reference's GPU path (NAN_LABEL = "cuda").  Through harness.compute_final_depth either
-    label makes the sample's geometric-mean normalisation non-finite (log of a negative number / of zero), as in the reference; the other
-    samples of the batch are untouched."""
+    label makes that SAMPLE's geometric-mean normalisation non-finite (log of a negative number / of zero), as in the reference
+    (module.py:119-133); the other samples of the batch are untouched."""
     from md_rdm_amd import harness
     utils = env["utils"]
     dep = np.full((2, 1, 8, 8), 2.0)
@@ -141,13 +141,14 @@ def test_sid_label_of_a_non_positive_depth_is_a_stated_option(env):
         lab = utils.depth2label_sid(g(dep, env), cuda=True).cpu().numpy()
         assert lab[0, 0, 3, 4] == 0 and lab[0, 0, 0, 0] == 0 and lab[1].min() == 66
         for mode in ("cpu", "cuda"):
+            # the step harness.compute_final_depth takes with these labels (module.py:126): normalize(depth2label_sid(resize(target, 8)))
             utils.NAN_LABEL = mode
             target = torch.full((2, 1, 128, 128), 2.0, dtype=torch.float64, device=env["dev"])
-            target[0, 0, 40:56, 40:56] = -0.25                       # an 8x8-resized block of it stays negative
-            fine = [torch.zeros(2, 1, 2 ** i, 2 ** i, device=env["dev"]) for i in range(4)]
-            final, _ = harness.compute_final_depth(fine, target, True)
-            f = final.cpu().numpy()
-            assert not np.isfinite(f[0]).all() and np.isfinite(f[1]).all(), mode
+            target[0, 0, 32:64, 32:64] = -0.25                       # the bicubic taps of one 8x8 output pixel (rows / columns 38..41) all fall inside
+            lab8 = utils.depth2label_sid(env["cp"].resize(target, 8), cuda=True)
+            assert int((lab8[0] == (np.iinfo(np.int32).min if mode == "cpu" else 0)).sum()) >= 1 and int(lab8[1].min()) == 66
+            nrm = harness.normalize(lab8).cpu().numpy()
+            assert not np.isfinite(nrm[0]).all() and np.isfinite(nrm[1]).all(), mode
     finally:
         utils.NAN_LABEL = "cpu"
 
