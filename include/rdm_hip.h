@@ -126,7 +126,7 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * points above; every float32 operand is split into two bf16 pieces at staging time and each product is formed as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores with float32 accumulation (error ~5e-6 of the result's maximum; the exact-f32
  * MFMA kernels: ~1e-6).  Gradients only - the forward pass never goes through these.  RDM_ERR_UNSUPPORTED for shapes without such a kernel
- * (1x1: 96 <= in_c <= 1536, in_c a multiple of 48; 3x3 / stride 1 / pad 1: out_c <= 48, rows of <= 93 pixels). */
+ * (1x1: 96 <= in_c <= 2304, in_c a multiple of 48; 3x3 / stride 1 / pad 1: out_c <= 48, rows of <= 93 pixels). */
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
@@ -285,8 +285,8 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                end of each of the 4 SEGMENTS only, not after every stage: for callers that do not consume gradients
  *                                stage by stage (no data-parallel exchange).  The gradients of a segment are complete on the caller's
  *                                stream once its last stage has returned.
- *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 8 192 pixels (dense_e2 / dense_e3 at the headline
- *                                geometry) run the split-precision bf16x3 kernels (rdm_conv2d_*_x3, csrc/xsplit.hip) instead of the exact-f32
+ *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 4 096 pixels (dense_e2 / e3 / e4 at the headline
+ *                                geometry; the 3x3 weight gradient from 8 192 pixels) run the split-precision bf16x3 kernels (rdm_conv2d_*_x3, csrc/xsplit.hip) instead of the exact-f32
  *                                MFMA kernels: gradients agree to ~5e-6 of a tensor's maximum, the forward pass is untouched.  Ignored in
  *                                deterministic mode. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,

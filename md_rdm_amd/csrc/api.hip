@@ -239,7 +239,7 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
-  if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 768)"); return RDM_ERR_UNSUPPORTED; }
+  if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 2304)"); return RDM_ERR_UNSUPPORTED; }
   return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
 }
 

@@ -1106,8 +1106,8 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   const int ntaps = taps ? a.g.KH * a.g.KW : 1;
   const long Mpix = (long)a.g.B * a.g.Ho * a.g.Wo;
   // split-precision (bf16x3) kernel where the caller allows it: long contractions only (the plan's many-pixel blocks)
-  if (a.xsplit && !t_deterministic && !taps && Mpix >= 8192 && xs_wgrad1x1_supported(a)) return launch_xs_wgrad1x1(a, s);
-  if (a.xsplit && !t_deterministic && taps && Mpix >= 8192 && xs_wgrad3x3_supported(a)) return launch_xs_wgrad3x3(a, s);
+  if (a.xsplit && !t_deterministic && !taps && Mpix >= 1024 && xs_wgrad1x1_supported(a)) return launch_xs_wgrad1x1(a, s);
+  if (a.xsplit && !t_deterministic && taps && Mpix >= 1024 && xs_wgrad3x3_supported(a)) return launch_xs_wgrad3x3(a, s);
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   // a ragged last column tile of the 128 x 96 config wastes up to 25 % of the MFMAs (C = 144: 2 x 96); 256 x 48 tiles fit every

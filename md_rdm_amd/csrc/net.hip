@@ -12,6 +12,7 @@
 //  * transitions pool before the (linear) 1x1 conv: 4x fewer GEMM rows.
 //  * everything needed by backward is kept (288 GB HBM: ~7 GB at B=16 228x304) instead of the
 //    reference's memory_efficient recomputation.
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -189,7 +190,13 @@ struct NetImpl {
   int opt_packed3x3 = 0;       // RDM_NET_OPT_PACKED_3X3: the 78 3x3 weights (and their gradients) are handed over as [tap][out][in]
   int opt_prezeroed = 0;       // RDM_NET_OPT_GRADS_PREZEROED: every gradient tensor is zero when backward stage 0 starts
   int opt_split_bwd = 0;       // RDM_NET_OPT_SPLIT_BWD: the backward GEMMs of the many-pixel blocks run the split-precision (bf16x3) kernels of xsplit.hip
-  bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= 8192; }
+  // blocks whose gradient GEMMs run the split-precision kernels: measured per block at B=16 228x304 - dense_e4 (4 560 pixels) gains on the 1x1
+  // weight / input gradients and the 3x3 input gradient (173 -> 100, 134 -> 86, 63 -> 45 us per layer) but not on the 3x3 weight gradient (51 -> 56 us);
+  // the decoder (1 280 pixels) loses overall (53.3 vs 52.6 ms per step)
+  int xs_min_pixels = 4096;
+  bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
+  int xs_wg3_min_pixels = 8192;
+  bool xs_block_wgrad3(int b) const { return xs_block(b) && bg[b].M >= xs_wg3_min_pixels; }
   // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
   struct Bf16Layer { size_t w1, w3, bn1, bn2; };
   std::vector<Bf16Layer> bfl[4];
@@ -317,7 +324,7 @@ struct NetImpl {
     winoQ = a.take<float>(winoQFloats);
     // split-precision backward (xsplit.hip): fragment-order split weights of the layer whose 3x3 input gradient is running (main stream)
     for (int b = 0; b < 4; ++b)
-      if (bg[b].M >= 8192) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
+      if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
@@ -584,7 +591,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       xw.g = geom3x3(n.B, g.H, g.W, 1);
       xw.G = go; xw.ldg = g.ctot; xw.N = GROWTH; xw.Xs = Y; xw.ldx = cb; xw.C = cb; xw.x_scale = bn2; xw.x_shift = bn2 + cb;
       xw.dW = dW3; xw.wtap = (long)GROWTH * cb; xw.ldw = cb; xw.xsplit = 1;
-      if (n.xs_block(b) && xs_wgrad3x3_supported(xw)) {
+      if (n.xs_block_wgrad3(b) && xs_wgrad3x3_supported(xw)) {
         // split-precision direct kernel: accumulates with f32 atomics into the zeroed gradient
         if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
         if ((rc = launch_xs_wgrad3x3(xw, side))) return rc;
@@ -750,7 +757,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
-  else if (option == RDM_NET_OPT_SPLIT_BWD) n->opt_split_bwd = value != 0;
+  else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }

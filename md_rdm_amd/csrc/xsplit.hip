@@ -80,7 +80,7 @@ struct XsWgradArgs {
   int M, split_k;
   unsigned g_bytes, x_bytes;
   int n_ctiles;                 // column tiles; tile t covers channels [ct_c0[t], ct_c0[t] + 16 * ct_nt[t])
-  int ct_c0[8], ct_nt[8];
+  int ct_c0[12], ct_nt[12];
 };
 
 constexpr int XS_BM = 128, XS_BK = 32, XS_NTMAX = 12;
@@ -523,7 +523,7 @@ struct XsDgrad1Args {
   int M, C, ksteps;
   int PT;                                  // 16-pixel tiles per workgroup
   int mtiles, ctiles;                      // pixel tiles x column tiles (<= 12 sixteen-channel tiles each)
-  int ct_c0[4], ct_n[4];                   // column tile t: first 16-channel tile, number of 16-channel tiles
+  int ct_c0[12], ct_n[12];                 // column tile t: first 16-channel tile, number of 16-channel tiles
   unsigned g_bytes, w_bytes, x_bytes;
 };
 
@@ -885,11 +885,11 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
 
 bool xs_wgrad1x1_supported(const WgradArgs& a) {
   const bool one = a.g.KH == 1 && a.g.KW == 1 && a.g.SH == 1 && a.g.SW == 1 && a.g.PH == 0 && a.g.PW == 0 && a.g.H == a.g.Ho && a.g.W == a.g.Wo;
-  return one && a.C % 48 == 0 && a.C >= 96 && a.C <= 8 * 192 && a.N % 4 == 0;
+  return one && a.C % 48 == 0 && a.C >= 96 && a.C <= 12 * 192 && a.N % 4 == 0;
 }
 
 int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
-  RDM_CHECK_ARG(xs_wgrad1x1_supported(a), "split-precision 1x1 wgrad: needs a 1x1 / stride 1 convolution with 96 <= C (%d) <= 1536, C a multiple of 48, N (%d) of 4", a.C, a.N);
+  RDM_CHECK_ARG(xs_wgrad1x1_supported(a), "split-precision 1x1 wgrad: needs a 1x1 / stride 1 convolution with 96 <= C (%d) <= 2304, C a multiple of 48, N (%d) of 4", a.C, a.N);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0 && ((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "split-precision 1x1 wgrad: strides multiples of 4 floats, operands 16-byte aligned");
   const long M = (long)a.g.B * a.g.Ho * a.g.Wo;
   const long gb = ((M - 1) * a.ldg + a.N) * 4, xb = ((M - 1) * a.ldx + a.C) * 4;
@@ -978,11 +978,11 @@ size_t xs_dgrad1x1_workspace_bytes(int K, int C) { return (size_t)2 * ((K + 31) 
 bool xs_dgrad1x1_supported(const FwdArgs& a) {
   const ConvGeom& g = a.g;
   const bool one = g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.PH == 0 && g.PW == 0 && g.H == g.Ho && g.W == g.Wo;
-  return one && a.N % 16 == 0 && a.N >= 16 && a.N <= 4 * X1_BNMAX && a.C % 4 == 0 && a.C >= 32 && a.bias == nullptr && !a.accumulate && !a.add_out;
+  return one && a.N % 16 == 0 && a.N >= 16 && a.N <= 12 * X1_BNMAX && a.C % 4 == 0 && a.C >= 32 && a.bias == nullptr && !a.accumulate && !a.add_out;
 }
 
 int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
-  RDM_CHECK_ARG(xs_dgrad1x1_supported(a), "split-precision 1x1 dgrad: needs a 1x1 / stride 1 convolution, 16 <= N (%d) <= %d a multiple of 16, C (%d) a multiple of 4", a.N, 4 * X1_BNMAX, a.C);
+  RDM_CHECK_ARG(xs_dgrad1x1_supported(a), "split-precision 1x1 dgrad: needs a 1x1 / stride 1 convolution, 16 <= N (%d) <= %d a multiple of 16, C (%d) a multiple of 4", a.N, 12 * X1_BNMAX, a.C);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 1x1 dgrad: plain or gate + statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
   RDM_CHECK_ARG(epi != EPI_MASK_STATS || (a.X && a.x_scale && a.x_shift && a.stat0 && a.stat1 && a.ldx % 4 == 0 && ((uintptr_t)a.X & 15) == 0), "split-precision 1x1 dgrad: the gate needs X, scale, shift and both statistics");

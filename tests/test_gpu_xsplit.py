@@ -29,6 +29,7 @@ WGRAD1_CASES = [
     (3, 57, 57, 144, 144, 200, False),       # one 144-channel tile, N < two row tiles, no prologue, 9 747 pixels (ragged last slab: not a multiple of 32)
     (2, 75, 73, 240, 272, 136, True),        # tiles 144 + 96, ld > C
     (5, 41, 43, 720, 768, 96, True),         # dense_e3's last layer width: 4 tiles (192 x 3 + 144), one row tile
+    (16, 15, 19, 2064, 2112, 720, True),     # dense_e4 conv1, last layer (RDM_Net.py:530): 11 column tiles, 4 560 pixels (142.5 slabs), deep K split
 ]
 
 
@@ -90,6 +91,7 @@ DGRAD3_CASES = [
     (6, 29, 38, 1392, 96),       # dense_e3 at its real width (RDM_Net.py:528): 14 x 96 + 48
     (3, 9, 7, 96, 48),           # tiny rows: the halo spans several image rows and image boundaries inside one tile
     (1, 66, 127, 192, 48),       # wide rows (LDS image 384 slots)
+    (16, 15, 19, 720, 2112),     # dense_e4 at the bench batch (RDM_Net.py:530): 144 work items for 512 persistent workgroups, 6 images in a tile
 ]
 
 
@@ -138,6 +140,7 @@ DGRAD1_CASES = [
     (16, 29, 38, 1392, 192, 768),    # dense_e3 conv1, first layer (RDM_Net.py:528): one column tile, 80-pixel tiles (an idle wave row)
     (3, 41, 43, 144, 96, 96),        # short K, 6 sixteen-channel tiles (3 + 3), 5 289 pixels: ragged last pixel tile
     (2, 33, 35, 1392, 720, 768),     # dense_e3's last layer width: 4 column tiles
+    (16, 15, 19, 720, 2064, 2112),   # dense_e4 conv1, last layer (RDM_Net.py:530): 11 column tiles, K = 22.5 steps
 ]
 
 

@@ -5,7 +5,7 @@ import torch
 import conftest
 
 pytestmark = pytest.mark.gpu
-NEED = {"test_gpu_conv": 4 + 4 + 8 + 2 + 4, "test_gpu_wino": 6 + 6, "test_gpu_xsplit": 5 + 4 + 4 + 4}          # headline-size parity cases each operator-level module must have run
+NEED = {"test_gpu_conv": 4 + 4 + 8 + 2 + 4, "test_gpu_wino": 6 + 6, "test_gpu_xsplit": 6 + 5 + 5 + 4}          # headline-size parity cases each operator-level module must have run
 
 
 def test_every_headline_kernel_variant_was_launched_by_a_parity_test():
