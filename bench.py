@@ -45,6 +45,7 @@ def main():
                     help="train = the headline metric (BASELINE configs[2]); fwd_bf16 = BASELINE configs[1], batch=8 forward-only bf16")
     ap.add_argument("--backward-precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="bf16x3 (default, what the package ships): the gradient GEMMs of dense_e2 / dense_e3 on the split-precision kernels; f32: exact-f32 MFMA everywhere")
+    ap.add_argument("--forward-split", type=int, default=1, help="1 (default, what the package ships): conv1 of dense_e2 / e3 on the three-way-split bf16x6 forward kernel (float32-equivalent); 0: f32 MFMA")
     ap.add_argument("--no-extra-configs", action="store_true", help="headline line only (skip BASELINE configs[1] and configs[4] at N=1)")
     args = ap.parse_args()
     if args.workload == "fwd_bf16":
@@ -144,6 +145,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
 
     model = DepthEstimationNet()
     model.backward_precision = args.backward_precision
+    model.forward_split = bool(args.forward_split)
     filler.fill_state_dict(model.state_dict())
     model = model.to(dev)
     model.train()
@@ -207,10 +209,10 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         # what each kernel family EXECUTES on the matrix pipe per algorithmic FLOP: the Winograd kernels (kinds 9, 10) multiply 1 / 2.25 as
         # much on the f32 pipe; the split-precision kernels (13-16) run three bf16 MFMAs per product on the bf16 pipe
         def pipe_of(kind):
-            return ("bf16", 3.0, PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
+            return ("bf16", 6.0 if kind == 17 else 3.0, PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
         per_kernel, busy_ms = [], 0.0
         executed_f32 = executed_bf16 = 0.0
-        for kind in list(range(11)) + [13, 14, 15, 16]:
+        for kind in list(range(11)) + [13, 14, 15, 16, 17]:
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:
@@ -295,12 +297,17 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         ms_step = elapsed / args.steps * 1e3
         out = {"metric": metric, "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.backward_precision == "f32" else "f32 (bf16x3-split gradient GEMMs)", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": ("f32" if args.backward_precision == "f32" and not args.forward_split else
+                                                                   "f32 (" + ", ".join(([] if not args.forward_split else ["bf16x6-split 1x1 forward of dense_e2/e3"]) +
+                                                                                      ([] if args.backward_precision == "f32" else ["bf16x3-split gradient GEMMs of dense_e2/e3/e4"])) + ")"), "data": "synthetic",
                "config": {"workload": f"{'KITTI' if (H, W) == (352, 1216) else 'NYU-v2'} {H}x{W} batch={B}/GPU full train step (fwd+losses+bwd+AdamW), DepthEstimationNet 90.5M params",
                           "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
-                          "precision": ("forward, losses, BatchNorm, AdamW: float32 (exact-f32 MFMA); weight / input gradient GEMMs of dense_e2 and dense_e3: float32 operands split "
-                                        "into bf16 hi + lo, three bf16 MFMAs per product, float32 accumulation (~5e-6 of a gradient's maximum vs ~1e-6 for the f32 kernels); "
-                                        "--backward-precision f32 runs every GEMM on the f32 pipe") if args.backward_precision != "f32" else "float32 everywhere (exact-f32 MFMA)",
+                          "precision": (("forward, losses, BatchNorm, AdamW: float32 - convolutions on the exact-f32 MFMA"
+                                         + (", except conv1 (1x1) of dense_e2 / dense_e3: operands split three ways into bf16, six bf16 MFMAs per product, float32 accumulation (float32-equivalent: "
+                                            "3-9e-7 of the result's maximum vs float64, the f32 kernel's own level); " if args.forward_split else "; ")
+                                         + ("weight / input gradient GEMMs of dense_e2 / e3 / e4: float32 operands split into bf16 hi + lo, three bf16 MFMAs per product, float32 accumulation "
+                                            "(~5e-6 of a gradient's maximum vs ~1e-6 for the f32 kernels)" if args.backward_precision != "f32" else "every gradient GEMM on the f32 pipe")
+                                         + "; --forward-split 0 --backward-precision f32 = float32 MFMA everywhere")),
                           "comm": comm},
                "roofline": roof, "cpu_baseline": cpu}
     return out

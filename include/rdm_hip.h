@@ -131,6 +131,12 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
                         float* dw_packed, int32_t split_k, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
  * sums when mask_x is given).  The workspace receives the split weights in MFMA-fragment order (re-formed on every call). */
+/* The dense layers' conv1 FORWARD (1x1 / stride 1; torchvision _DenseLayer.conv1 reached from network/RDM_Net.py:526-530) with a THREE-way split -
+ * six bf16 MFMAs per product, float32-equivalent accuracy (the two-way split of the gradient kernels is not accurate enough for the forward's 1e-4
+ * parity): operands and meaning of rdm_conv2d_fwd without bias (BatchNorm + ReLU prologue on x, optional per-channel sums of y and y^2). */
+size_t rdm_conv1x1_fwd_x6_workspace_bytes(int32_t in_c, int32_t out_c);
+int rdm_conv1x1_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
+                       double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
 size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c);
 int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
                          int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,
@@ -288,9 +294,11 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 4 096 pixels (dense_e2 / e3 / e4 at the headline
  *                                geometry; the 3x3 weight gradient from 8 192 pixels) run the split-precision bf16x3 kernels (rdm_conv2d_*_x3, csrc/xsplit.hip) instead of the exact-f32
  *                                MFMA kernels: gradients agree to ~5e-6 of a tensor's maximum, the forward pass is untouched.  Ignored in
- *                                deterministic mode. */
+ *                                deterministic mode.
+ *   RDM_NET_OPT_SPLIT_FWD        the 1x1 convolutions (conv1) of the dense blocks with >= 8 192 pixels run the three-way-split bf16x6 kernel
+ *                                (rdm_conv1x1_fwd_x6) in rdm_net_forward: float32-equivalent accuracy, write-bound instead of f32-MFMA-bound. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -223,6 +223,24 @@ int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   return launch_xs_dgrad3x3(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
 }
 
+size_t rdm_conv1x1_fwd_x6_workspace_bytes(int32_t in_c, int32_t out_c) { return out_c > 0 && in_c > 0 ? xs_fwd1x1_workspace_bytes(in_c, out_c) : 0; }
+
+int rdm_conv1x1_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y, double* stat_sum,
+                       double* stat_sq, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(x && w && y, "conv1x1_fwd_x6: NULL operand");
+  RDM_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "conv1x1_fwd_x6: both statistics or none");
+  FwdArgs a{};
+  a.g = g; a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift;
+  a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.out = y; a.ldc = d->out_ld; a.M = d->batch * g.Ho * g.Wo; a.N = d->out_c;
+  a.stat0 = stat_sum; a.stat1 = stat_sq;
+  if (!xs_fwd1x1_supported(a)) { set_error("conv1x1_fwd_x6: no split-precision kernel for this convolution (1x1 / stride 1, out_c a multiple of 16, in_c of 4)"); return RDM_ERR_UNSUPPORTED; }
+  return launch_xs_fwd1x1(a, stat_sum ? EPI_STORE_STATS : EPI_STORE, workspace, workspace_bytes, stream);
+}
+
 size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c) { return out_c > 0 && in_c > 0 ? xs_dgrad1x1_workspace_bytes(out_c, in_c) : 0; }
 
 int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,

@@ -180,7 +180,7 @@ struct NetImpl {
   int wino_split[4] = {1, 1, 1, 1};
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
-  size_t xsW = 0, xsWBytes = 0;
+  size_t xsW = 0, xsWBytes = 0, xfW = 0, xfWBytes = 0;
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
@@ -195,6 +195,9 @@ struct NetImpl {
   // the decoder (1 280 pixels) loses overall (53.3 vs 52.6 ms per step)
   int xs_min_pixels = 4096;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
+  int opt_split_fwd = 0;       // RDM_NET_OPT_SPLIT_FWD: conv1 of the many-pixel blocks on the three-way-split bf16x6 forward kernel
+  int xf_min_pixels = 8192;
+  bool xf_block(int b) const { return opt_split_fwd && !opt_det && bg[b].M >= xf_min_pixels; }
   int xs_wg3_min_pixels = 8192;
   bool xs_block_wgrad3(int b) const { return xs_block(b) && bg[b].M >= xs_wg3_min_pixels; }
   // ---- reduced-precision forward (bf16.hip): prepared-weight buffer layout + activation workspace layout ----
@@ -326,6 +329,9 @@ struct NetImpl {
     for (int b = 0; b < 4; ++b)
       if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
+    for (int b = 0; b < 4; ++b)
+      if (bg[b].M >= 1024) xfWBytes = std::max(xfWBytes, xs_fwd1x1_workspace_bytes(bg[b].ctot, bg[b].cb));
+    xfW = a.take<unsigned char>(xfWBytes);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
     for (int b = 0; b < 4; ++b) {
@@ -409,6 +415,8 @@ int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, b
     a.a_scale = nullptr; a.a_shift = nullptr;
     a.a_sum = bst + c_lo; a.a_sq = bst + g.ctot + c_lo; a.a_gamma = F(T, L.bn1.w) + c_lo; a.a_beta = F(T, L.bn1.b) + c_lo; a.a_count = (double)g.M;
   }
+  if (n.xf_block(b) && !accumulate && !add_out && !raw_bn && xs_fwd1x1_supported(a))
+    return launch_xs_fwd1x1(a, fuse ? EPI_STORE_STATS : EPI_STORE, at<unsigned char>(ws, n.xfW), n.xfWBytes, s);
   const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
   return rc < 0 ? rc : 0;
 }
@@ -758,6 +766,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
   else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
+  else if (option == RDM_NET_OPT_SPLIT_FWD) { n->opt_split_fwd = value != 0; if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = atoi(getenv("RDM_XF_MIN_PIXELS")); }
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }

@@ -17,4 +17,9 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
 // 3x3 / stride 1 / pad 1 weight gradient with <= 48 output channels: operands and meaning of launch_conv_wgrad (dW pre-zeroed, accumulated)
 bool xs_wgrad3x3_supported(const WgradArgs& a);
 int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s);
+// 1x1 / stride 1 FORWARD with a three-way split (six bf16 MFMAs per product: float32-equivalent); FwdArgs as launch_conv_fwd takes them
+// (A = input [M][C] with the BatchNorm + ReLU prologue, Wt = weights [N][C], out = [M][N]); epi = EPI_STORE or EPI_STORE_STATS
+bool xs_fwd1x1_supported(const FwdArgs& a);
+size_t xs_fwd1x1_workspace_bytes(int K, int N);
+int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s);
 }  // namespace rdm

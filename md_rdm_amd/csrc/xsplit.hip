@@ -881,6 +881,216 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
       }
 }
 
+
+// =============================================================================================
+// 1x1 FORWARD of the dense layers' conv1:  Y[m][n] = sum_c f(X[m][c]) * W[n][c]  (c: the layer's Cin input channels = a prefix of the block
+// buffer's rows; n: the Cb bottleneck channels), f = ReLU(BatchNorm), optional per-channel sums of Y and Y^2 (training-mode statistics).
+// THREE-way split ("bf16x6"): x = x0 + x1 + x2 exactly (8 + 8 + 8 significant bits), products x0 w0 + x0 w1 + x1 w0 + x0 w2 + x2 w0 + x1 w1 -
+// six bf16 MFMAs, float32-equivalent accuracy (dropped terms 2^-24 relative; measured on the reference fixtures: logits within 7.7e-6 of their
+// maximum, where the two-way split of the gradient kernels gives 1.0e-4 - too much for the forward's 1e-4 parity bar).  Still 2.7x less
+// matrix-pipe time than the f32 MFMA, and this convolution is bound by WRITING Y (758 MB per dense_e2 layer), not by the pipe.
+// Structure of xs_dgrad1x1_kernel (8 waves, [row][32 k] images with 3 planes per operand, pre-split weights copied verbatim) with ONE LDS stage
+// (84 KB) and two barriers per k-step; 256-pixel x 192-channel tiles.  Measured alternatives (in-process, dense_e2 / dense_e3 shapes): two stages with
+// 128-channel tiles - dense_e2 0.42 / 0.61 / 0.94 ms at K = 96 / 192 / 336 against this form's 0.36 / 0.52 / 0.83 (more re-staging of the input per
+// output), dense_e3 0.08-0.22 against 0.09-0.25; a persistent workgroup per pixel tile walking its column tiles (stores of tile t draining under
+// tile t + 1): 0.47 / 0.63 / 0.96 and half the speed at dense_e3 (one 80-pixel workgroup per CU).  The f32 kernel: 0.45 / 0.70 / 1.15.
+// =============================================================================================
+constexpr int XF_MTW = 4, XF_NTW = 6, XF_PTMAX = 4 * XF_MTW, XF_BMMAX = XF_PTMAX * 16, XF_BNMAX = 2 * XF_NTW * 16;
+constexpr int XF_X_IMG = XF_BMMAX * 64, XF_W_IMG = XF_BNMAX * 64;
+constexpr int XF_LDS = 3 * XF_X_IMG + 3 * XF_W_IMG;      // one stage: 84 KB
+
+struct XsFwd1Args {
+  const float* X; int ldx; int K;          // block buffer [M][ldx], K = Cin contracted channels
+  const float* x_scale; const float* x_shift;
+  const unsigned char* Wp;                 // [plane 0..2][ksteps][N][64 B]
+  float* out; int ldc;
+  double* stat0; double* stat1;
+  int M, N, ksteps, PT, mtiles, ctiles;
+  unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ void split3x4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  const bf16x2 a01 = {(__bf16)v[0], (__bf16)v[1]}, a23 = {(__bf16)v[2], (__bf16)v[3]};
+  const float r0 = v[0] - (float)a01[0], r1 = v[1] - (float)a01[1], r2 = v[2] - (float)a23[0], r3 = v[3] - (float)a23[1];
+  const bf16x2 b01 = {(__bf16)r0, (__bf16)r1}, b23 = {(__bf16)r2, (__bf16)r3};
+  const float q0 = r0 - (float)b01[0], q1 = r1 - (float)b01[1], q2 = r2 - (float)b23[0], q3 = r3 - (float)b23[1];
+  const bf16x2 c01 = {(__bf16)q0, (__bf16)q1}, c23 = {(__bf16)q2, (__bf16)q3};
+  p0 = u32x2{__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23)};
+  p1 = u32x2{__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23)};
+  p2 = u32x2{__builtin_bit_cast(unsigned, c01), __builtin_bit_cast(unsigned, c23)};
+}
+
+__global__ __launch_bounds__(256) void k_xs_pack_w1_fwd(const float* __restrict__ w, int ldw, int N, int K, int ksteps, unsigned char* __restrict__ Wp) {
+  // one thread per (k-step, n, 8-k chunk): 8 consecutive weights of row n -> 16 B of each of the three planes at the swizzled chunk
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ch = (int)(idx & 3);
+  const long r1 = idx >> 2;
+  const int n = (int)(r1 % N), j = (int)(r1 / N);
+  if (j >= ksteps) return;
+  f32x4 v0, v1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k0 = 32 * j + 8 * ch + e, k1 = k0 + 4;
+    v0[e] = k0 < K ? w[(long)n * ldw + k0] : 0.f;
+    v1[e] = k1 < K ? w[(long)n * ldw + k1] : 0.f;
+  }
+  u32x2 a0, a1, a2, b0, b1, b2;
+  split3x4(v0, a0, a1, a2);
+  split3x4(v1, b0, b1, b2);
+  const int chs = ch ^ (((n >> 2) & 1) << 1);
+  const long plane = (long)ksteps * N * 64;
+  unsigned char* dst = Wp + ((long)j * N + n) * 64 + chs * 16;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{a0[0], a0[1], b0[0], b0[1]};
+  *reinterpret_cast<u32x4*>(dst + plane) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+  *reinterpret_cast<u32x4*>(dst + 2 * plane) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(512, 2) void xs_fwd1x1_kernel(XsFwd1Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char xf_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wc = wave & 1, wp = wave >> 1;
+  // work item = (pixel tile, column tile of 192 outputs), column tile fastest: the workgroups of one pixel tile run side by side and its input
+  // rows are fetched from HBM once; XCD x works through a contiguous range of items
+  const unsigned total = gridDim.x, L = blockIdx.x, xq = L & 7u, qq = total >> 3, rr = total & 7u;
+  const unsigned item = xq * qq + (xq < rr ? xq : rr) + (L >> 3);
+  const int mt = (int)(item / (unsigned)p.ctiles), ctile = (int)(item - (unsigned)mt * (unsigned)p.ctiles);
+  const int BM = p.PT * 16, m0 = mt * BM;
+  const int ct0 = ctile * (2 * XF_NTW), nct = min(2 * XF_NTW, p.N / 16 - ct0), BN = nct * 16;
+  const int ntw_max = (nct + 1) >> 1, tw0 = wc * ntw_max, ntw = min(ntw_max, nct - tw0);
+  const int npw_max = (p.PT + 3) >> 2, pw0 = wp * npw_max, npw = max(0, min(npw_max, p.PT - pw0));
+  const __amdgpu_buffer_rsrc_t srdX = xsrd(p.X, p.x_bytes), srdW = xsrd(p.Wp, p.w_bytes);
+  const bool bnrelu = p.x_scale != nullptr;
+  unsigned char* const Xi = xf_smem;                          // 3 planes of XF_X_IMG
+  unsigned char* const Wi = xf_smem + 3 * XF_X_IMG;           // 3 planes of XF_W_IMG
+
+  unsigned x_voff[XF_MTW]; unsigned x_lds[XF_MTW]; bool x_ok[XF_MTW];
+  const int f4 = tid & 7;                                     // this thread's float4 of a row's 32 k: the same for all its rows
+#pragma unroll
+  for (int u = 0; u < XF_MTW; ++u) {
+    const int row = (tid + 512 * u) >> 3;
+    x_ok[u] = row < BM && m0 + row < p.M;
+    x_voff[u] = (unsigned)(m0 + row) * (unsigned)(p.ldx * 4) + (unsigned)(f4 * 16);
+    x_lds[u] = (unsigned)(row * 64 + (((f4 >> 1) ^ (((row >> 2) & 1) << 1)) * 16) + (f4 & 1) * 8);
+  }
+  const int wpieces = BN * 4;                                 // 16-byte pieces of ONE plane of the weight slab
+  const unsigned w_plane = (unsigned)p.ksteps * (unsigned)p.N * 64u;
+  f32x4 rx[XF_MTW], sc, sh; u32x4 rw[5];                       // weight pieces: 3 planes x BN x 4 <= 2304 = 4.5 per thread
+  auto load_slab = [&](int j) {
+    const bool kok = 32 * j + 4 * f4 < p.K;
+#pragma unroll
+    for (int u = 0; u < XF_MTW; ++u)
+      rx[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (int)((x_ok[u] && kok) ? x_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
+    if (bnrelu) {
+      sc = kok ? *reinterpret_cast<const f32x4*>(p.x_scale + 32 * j + 4 * f4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      sh = kok ? *reinterpret_cast<const f32x4*>(p.x_shift + 32 * j + 4 * f4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int q = tid + 512 * u, pl = q / wpieces, r = q - pl * wpieces;        // piece r of plane pl
+      rw[u] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(q < 3 * wpieces ? (unsigned)pl * w_plane + ((unsigned)j * (unsigned)p.N + (unsigned)(ct0 * 16)) * 64u + (unsigned)r * 16u : XOOB), 0, 0);
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int u = 0; u < XF_MTW; ++u) {
+      if ((tid + 512 * u) >> 3 < BM) {
+        f32x4 v = rx[u];
+        if (bnrelu) {
+          // a dead element (k past K: loaded as 0, coefficients 0) stays exactly 0; rows past M are never stored
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+        }
+        u32x2 p0, p1, p2;
+        split3x4(v, p0, p1, p2);
+        *reinterpret_cast<u32x2*>(Xi + x_lds[u]) = p0;
+        *reinterpret_cast<u32x2*>(Xi + XF_X_IMG + x_lds[u]) = p1;
+        *reinterpret_cast<u32x2*>(Xi + 2 * XF_X_IMG + x_lds[u]) = p2;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int q = tid + 512 * u, pl = q / wpieces, r = q - pl * wpieces;
+      if (q < 3 * wpieces) *reinterpret_cast<u32x4*>(Wi + pl * XF_W_IMG + r * 16) = rw[u];
+    }
+  };
+
+  f32x4 acc[XF_MTW][XF_NTW];
+#pragma unroll
+  for (int i = 0; i < XF_MTW; ++i)
+#pragma unroll
+    for (int t = 0; t < XF_NTW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned fr = (unsigned)(l16 * 64 + ((g ^ (((l16 >> 2) & 1) << 1)) * 16));
+
+  load_slab(0);
+  for (int j = 0; j < p.ksteps; ++j) {
+    store_slab();
+    __syncthreads();
+    if (j + 1 < p.ksteps) load_slab(j + 1);                     // in flight under this slab's MFMAs
+    bf16x8 x0[XF_MTW], x1[XF_MTW], x2[XF_MTW];
+#pragma unroll
+    for (int i = 0; i < XF_MTW; ++i)
+      if (i < npw) {
+        x0[i] = *reinterpret_cast<const bf16x8*>(Xi + (pw0 + i) * 1024 + fr);
+        x1[i] = *reinterpret_cast<const bf16x8*>(Xi + XF_X_IMG + (pw0 + i) * 1024 + fr);
+        x2[i] = *reinterpret_cast<const bf16x8*>(Xi + 2 * XF_X_IMG + (pw0 + i) * 1024 + fr);
+      }
+#pragma unroll
+    for (int t = 0; t < XF_NTW; ++t)
+      if (t < ntw) {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(Wi + (tw0 + t) * 1024 + fr);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(Wi + XF_W_IMG + (tw0 + t) * 1024 + fr);
+        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(Wi + 2 * XF_W_IMG + (tw0 + t) * 1024 + fr);
+#pragma unroll
+        for (int i = 0; i < XF_MTW; ++i)
+          if (i < npw) {                                        // smallest terms first
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x0[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x2[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x0[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1[i], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0[i], acc[i][t], 0, 0, 0);
+          }
+      }
+    __syncthreads();                                            // every wave is past its reads of the images
+  }
+
+  // ---- epilogue: a lane owns output channels n4 .. n4 + 3 (D rows 4 g + r) of pixel m (D column l16) ----
+#pragma unroll
+  for (int t = 0; t < XF_NTW; ++t) {
+    if (t >= ntw) continue;
+    const int n4 = (ct0 + tw0 + t) * 16 + 4 * g;
+    const bool nok = n4 < p.N;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < XF_MTW; ++i) {
+      const int m = m0 + (pw0 + i) * 16 + l16;
+      const bool ok = nok && i < npw && m < p.M;
+      const f32x4 v = acc[i][t];
+      if (ok) {
+        *reinterpret_cast<f32x4*>(p.out + (long)m * p.ldc + n4) = v;       // (plain global stores: see the note in xs_dgrad3x3_kernel)
+        if (STATS) { s0 += v; s1 += v * v; }
+      }
+    }
+    if (STATS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = s0[e], b = s1[e];
+        a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+        a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+        a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+        a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+        if (l16 == e) { s0[0] = a; s1[0] = b; }
+      }
+      if (l16 < 4 && nok && npw > 0) {
+        atomicAdd(p.stat0 + n4 + l16, (double)s0[0]);
+        atomicAdd(p.stat1 + n4 + l16, (double)s1[0]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool xs_wgrad1x1_supported(const WgradArgs& a) {
@@ -1061,6 +1271,57 @@ int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * 9.0 * a.C, 15);
   RDM_CENSUS("xs_wgrad3x3_kernel/%s", a.x_scale ? "bn1" : "bn0");
   hipLaunchKernelGGL(xs_wgrad3x3_kernel, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
+  profile_end(prof, s);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+size_t xs_fwd1x1_workspace_bytes(int K, int N) { return (size_t)3 * ((K + 31) / 32) * N * 64; }
+
+bool xs_fwd1x1_supported(const FwdArgs& a) {
+  const ConvGeom& g = a.g;
+  const bool one = g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1 && g.PH == 0 && g.PW == 0 && g.H == g.Ho && g.W == g.Wo && g.dir == 1;
+  return one && a.N % 16 == 0 && a.N >= 16 && a.C % 4 == 0 && a.C >= 4 && a.bias == nullptr && !a.accumulate && !a.add_out && a.a_sum == nullptr;
+}
+
+int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+  RDM_CHECK_ARG(xs_fwd1x1_supported(a), "split-precision 1x1 forward: needs a 1x1 / stride 1 convolution, N (%d) a multiple of 16, C (%d) a multiple of 4, no bias / accumulation", a.N, a.C);
+  RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_STORE_STATS, "split-precision 1x1 forward: plain or statistics epilogue only");
+  RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 forward: strides multiples of 4 floats, tensors 16-byte aligned");
+  RDM_CHECK_ARG((a.a_scale == nullptr) == (a.a_shift == nullptr) && (a.a_scale == nullptr || (((uintptr_t)a.a_scale | (uintptr_t)a.a_shift) & 15) == 0), "split-precision 1x1 forward: scale and shift go together, 16-byte aligned");
+  RDM_CHECK_ARG(epi != EPI_STORE_STATS || (a.stat0 && a.stat1), "split-precision 1x1 forward: the statistics epilogue needs both sums");
+  const int K = a.C, N = a.N, ksteps = (K + 31) / 32;
+  RDM_CHECK_ARG(ws != nullptr && ((uintptr_t)ws & 15) == 0 && ws_bytes >= xs_fwd1x1_workspace_bytes(K, N), "split-precision 1x1 forward: workspace too small or misaligned (%zu < %zu)", ws_bytes, xs_fwd1x1_workspace_bytes(K, N));
+  const long M = a.M;
+  const long xb = ((M - 1) * a.lda + K) * 4;
+  if (xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 forward: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  {
+    const long threads = (long)ksteps * N * 4;
+    hipLaunchKernelGGL(k_xs_pack_w1_fwd, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.ldw, N, K, ksteps, static_cast<unsigned char*>(ws));
+    RDM_LAUNCH_OK();
+  }
+  XsFwd1Args k{};
+  k.X = a.A; k.ldx = a.lda; k.K = K; k.x_scale = a.a_scale; k.x_shift = a.a_shift; k.Wp = static_cast<const unsigned char*>(ws);
+  k.out = a.out; k.ldc = a.ldc; k.stat0 = a.stat0; k.stat1 = a.stat1; k.M = (int)M; k.N = N; k.ksteps = ksteps;
+  k.ctiles = cdiv(N / 16, 2 * XF_NTW);
+  int best_pt = 1; long best_cost = -1;
+  for (int pt = 1; pt <= XF_PTMAX; ++pt) {
+    const long items = (long)cdiv(M, 16 * pt) * k.ctiles, rounds = (items + 255) / 256;
+    const long cost = rounds * (pt * 16 + 24);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pt = pt; }
+  }
+  k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
+  k.x_bytes = (unsigned)xb; k.w_bytes = (unsigned)xs_fwd1x1_workspace_bytes(K, N);
+  void* prof = profile_begin(s, 2.0 * (double)M * N * K, 17);
+  RDM_CENSUS("xs_fwd1x1_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", epi == EPI_STORE_STATS ? "STORE_STATS" : "STORE");
+  const dim3 grid((unsigned)(k.mtiles * k.ctiles));
+  if (epi == EPI_STORE_STATS) {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS));
+    hipLaunchKernelGGL(xs_fwd1x1_kernel<true>, grid, dim3(512), XF_LDS, s, k);
+  } else {
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS));
+    hipLaunchKernelGGL(xs_fwd1x1_kernel<false>, grid, dim3(512), XF_LDS, s, k);
+  }
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;

@@ -224,3 +224,47 @@ def test_xs_wgrad3x3_vs_float64(case):
         err = rel(dw.cpu().double(), want)
         assert err < TOL, (split, err)
     _RAN.add(("xs_wgrad3x3", case))
+
+
+FWD1_CASES = [
+    # B, H, W, K (= Cin), ldx, N (= Cb), bn
+    (4, 57, 76, 336, 384, 2736, True),       # dense_e2 conv1, last layer (RDM_Net.py:526): 15 column tiles (14 x 192 + 48), K = 10.5 steps, NaN behind the prefix
+    (16, 29, 38, 192, 768, 1392, True),      # dense_e3 conv1, first layer (RDM_Net.py:528)
+    (3, 41, 43, 96, 96, 208, False),         # no prologue, N = 13 sixteen-channel tiles (one full column tile + a 16-wide one), ragged pixel tile
+    (2, 33, 35, 720, 768, 96, True),         # long K (22.5 steps), one narrow column tile
+]
+
+
+@pytest.mark.parametrize("case", FWD1_CASES, ids=[f"f1x1_{i}" for i in range(len(FWD1_CASES))])
+def test_xs_fwd1x1_x6_vs_float64(case):
+    """xs_fwd1x1_kernel (three-way split, six bf16 MFMAs per product) against a float64 product at the tolerance of the f32 MFMA kernel it can
+    replace in the FORWARD pass (2e-5 of the maximum; measured ~1e-6: float32-equivalent), with and without the statistics epilogue."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, K, ld, N, bn = case
+    M = B * H * W
+    g = torch.Generator().manual_seed(8000 + K)
+    x = torch.randn(M, ld, generator=g)
+    x[:, K:] = float("nan")
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    sc = torch.rand(K, generator=g) + 0.5
+    sh = torch.randn(K, generator=g) * 0.3
+    a = (torch.relu(x[:, :K] * sc + sh) if bn else x[:, :K]).double()
+    want = a @ w.double().t()
+    d = ConvDesc(B, H, W, K, ld, N, N, 1, 1, 1, 1, 0, 0)
+    xg, wg, scg, shg = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    wsb = L.rdm_conv1x1_fwd_x6_workspace_bytes(K, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    for stats in (True, False):
+        y = torch.full((M, N), float("nan"), device=dev)
+        ssum = torch.zeros(N, dtype=torch.float64, device=dev)
+        ssq = torch.zeros_like(ssum)
+        check(L.rdm_conv1x1_fwd_x6(C.byref(d), ptr(xg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(y),
+                                   ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), wsb, stream()))
+        err = rel(y.cpu().double(), want)
+        assert err < 2e-6, err                       # float32-equivalent: an order of magnitude inside the f32 kernels' 2e-5 gate
+        if stats:
+            assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
+    _RAN.add(("xs_fwd1x1", case))

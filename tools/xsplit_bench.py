@@ -121,6 +121,36 @@ def wg3(B, H, W, Cb):
           f"| x3 vs winograd f32 {diff:.1e} | speedup {t['f32']/t['x3']:.2f}x", flush=True)
 
 
+def fw1(B, H, W, Cb, cin, ld):
+    M = B * H * W
+    X = torch.randn(M, ld, device=dev)
+    w1 = torch.randn(Cb, cin, device=dev) * 0.05
+    sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.3
+    d = ConvDesc(B, H, W, cin, ld, Cb, Cb, 1, 1, 1, 1, 0, 0)
+    Y = torch.empty(M, Cb, device=dev)
+    s0 = torch.zeros(Cb, dtype=torch.float64, device=dev); s1 = torch.zeros_like(s0)
+    wsb = L.rdm_conv1x1_fwd_x6_workspace_bytes(cin, Cb)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    def f32(): check(L.rdm_conv2d_fwd(C.byref(d), ptr(X), ptr(w1), None, ptr(sc), ptr(sh), ptr(Y), ptr(s0), ptr(s1), stream()))
+    def x6(): check(L.rdm_conv1x1_fwd_x6(C.byref(d), ptr(X), ptr(w1), ptr(sc), ptr(sh), ptr(Y), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    a = torch.relu(X[:8192, :cin].double() * sc.double() + sh.double())
+    want = a @ w1.double().t()
+    errs = {}
+    for k, fn in (("f32", f32), ("x6", x6)):
+        fn(); torch.cuda.synchronize()
+        errs[k] = ((Y[:8192].double() - want).abs().max() / want.abs().max()).item()
+    t = timeit({"f32": f32, "x6": x6})
+    fl = 2.0 * M * Cb * cin
+    by = 4.0 * M * (Cb + cin)
+    print(f"fw1 M={M} N={Cb} K={cin}: f32 {t['f32']*1e3:.3f} ms {fl/t['f32']/1e12:.0f} TF err {errs['f32']:.1e} | x6 {t['x6']*1e3:.3f} ms {fl/t['x6']/1e12:.0f} TF-equiv "
+          f"({by/t['x6']/1e12:.2f} TB/s algorithmic) err {errs['x6']:.1e} | speedup {t['f32']/t['x6']:.2f}x", flush=True)
+
+
+if which in ("fw1", "all"):
+    for cin in (96, 192, 336):
+        fw1(16, 57, 76, 2736, cin, 384)
+    for cin in (192, 480, 720):
+        fw1(16, 29, 38, 1392, cin, 768)
 if which in ("wg3", "all"):
     wg3(16, 57, 76, 2736)
     wg3(16, 29, 38, 1392)
