@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--backward-precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="bf16x3 (default, what the package ships): the gradient GEMMs of dense_e2 / dense_e3 on the split-precision kernels; f32: exact-f32 MFMA everywhere")
     ap.add_argument("--forward-split", type=int, default=1, help="1 (default, what the package ships): conv1 of dense_e2 / e3 on the three-way-split bf16x6 forward kernel (float32-equivalent); 0: f32 MFMA")
+    ap.add_argument("--gemm-bf16", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="MIXED-PRECISION arithmetic (the reference's default --precision 16): the GEMMs the two options above route to the split kernels round their operands to bf16, "
+                    "one MFMA per product. 1: forward and gradient GEMMs, 2: forward only, 3: gradient GEMMs only. NOT the parity configuration - a separately labelled line, never the headline")
     ap.add_argument("--no-extra-configs", action="store_true", help="headline line only (skip BASELINE configs[1] and configs[4] at N=1)")
     args = ap.parse_args()
     if args.workload == "fwd_bf16":
@@ -76,6 +79,15 @@ def main():
         a3.steps, a3.warmup = min(args.steps, 5), min(args.warmup, 2)
         e = bench_train(a3, 8, 352, 1216, with_cpu_baseline=False, metric="depth-maps/sec KITTI 352x1216 batch=8 fwd+bwd")
         extra.append({k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")})
+        if not args.gemm_bf16:
+            # the headline geometry once more in the mixed-precision arithmetic mode (reference default --precision 16, train.py:11,57-58)
+            release()
+            for mode, what in ((1, "forward + gradient GEMMs"), (3, "gradient GEMMs only")):
+                a4 = argparse.Namespace(**vars(args))
+                a4.gemm_bf16 = mode
+                e = bench_train(a4, 16, 228, 304, with_cpu_baseline=False, metric=f"depth-maps/sec NYU 228x304 batch=16 fwd+bwd, mixed precision (bf16 operands: {what})")
+                extra.append({k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")})
+                release()
         # nested under `config`: the driver's record keeps nested keys of the line, not new top-level ones
         out["config"]["extra_configs"] = extra
     if out is not None:
@@ -146,6 +158,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
     model = DepthEstimationNet()
     model.backward_precision = args.backward_precision
     model.forward_split = bool(args.forward_split)
+    model.gemm_bf16 = int(args.gemm_bf16)
     filler.fill_state_dict(model.state_dict())
     model = model.to(dev)
     model.train()
@@ -209,7 +222,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         # what each kernel family EXECUTES on the matrix pipe per algorithmic FLOP: the Winograd kernels (kinds 9, 10) multiply 1 / 2.25 as
         # much on the f32 pipe; the split-precision kernels (13-16) run three bf16 MFMAs per product on the bf16 pipe
         def pipe_of(kind):
-            return ("bf16", 6.0 if kind == 17 else 3.0, PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
+            return ("bf16", (1.0 if args.gemm_bf16 in (1, 2) else 6.0) if kind == 17 else (1.0 if args.gemm_bf16 in (1, 3) else 3.0), PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
         per_kernel, busy_ms = [], 0.0
         executed_f32 = executed_bf16 = 0.0
         for kind in list(range(11)) + [13, 14, 15, 16, 17]:
@@ -297,12 +310,21 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         ms_step = elapsed / args.steps * 1e3
         out = {"metric": metric, "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": ("f32" if args.backward_precision == "f32" and not args.forward_split else
+               "scaling": "weak", "vs_baseline": None, "dtype": ("bf16-mixed (bf16 GEMM operands, f32 accumulation, in " + {1: "dense_e2/e3 conv1 forward and the gradient GEMMs of dense_e2/e3/e4", 2: "dense_e2/e3 conv1 forward",
+                                                                                                                                    3: "the gradient GEMMs of dense_e2/e3/e4"}[args.gemm_bf16] + "; all else f32)" if args.gemm_bf16 else "f32" if args.backward_precision == "f32" and not args.forward_split else
                                                                    "f32 (" + ", ".join(([] if not args.forward_split else ["bf16x6-split 1x1 forward of dense_e2/e3"]) +
                                                                                       ([] if args.backward_precision == "f32" else ["bf16x3-split gradient GEMMs of dense_e2/e3/e4"])) + ")"), "data": "synthetic",
                "config": {"workload": f"{'KITTI' if (H, W) == (352, 1216) else 'NYU-v2'} {H}x{W} batch={B}/GPU full train step (fwd+losses+bwd+AdamW), DepthEstimationNet 90.5M params",
                           "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss.item()),
-                          "precision": (("forward, losses, BatchNorm, AdamW: float32 - convolutions on the exact-f32 MFMA"
+                          "precision": ("MIXED (not the parity configuration): " + {1: "the 1x1 forward GEMMs of dense_e2 / e3 and the weight / input gradient GEMMs of dense_e2 / e3 / e4",
+                                                                                                   2: "the 1x1 forward GEMMs of dense_e2 / e3", 3: "the weight / input gradient GEMMs of dense_e2 / e3 / e4"}[args.gemm_bf16] +
+                                        " round their float32 operands to bf16 (ONE bf16 MFMA per product, float32 accumulation); activations, weights, BatchNorm statistics, every other convolution, "
+                                        "losses and AdamW stay float32. Measured against the default path at B=4 228x304 (tests/test_gpu_mixed.py): " +
+                                        ("logits identical, every gradient tensor's cosine >= 0.9999, loss after 4 AdamW steps within 0.1 %" if args.gemm_bf16 == 3 else
+                                         "logits RMS 3.2 % (36 bf16 GEMMs under training-mode BatchNorm), gradient cosine 0.84 .. 1.0 per tensor (the FORWARD rounding moves the loss gradient: "
+                                         "gradient-only rounding keeps >= 0.9999), loss after 4 AdamW steps within 1 %")
+                                        if args.gemm_bf16 else
+                                        ("forward, losses, BatchNorm, AdamW: float32 - convolutions on the exact-f32 MFMA"
                                          + (", except conv1 (1x1) of dense_e2 / dense_e3: operands split three ways into bf16, six bf16 MFMAs per product, float32 accumulation (float32-equivalent: "
                                             "3-9e-7 of the result's maximum vs float64, the f32 kernel's own level); " if args.forward_split else "; ")
                                          + ("weight / input gradient GEMMs of dense_e2 / e3 / e4: float32 operands split into bf16 hi + lo, three bf16 MFMAs per product, float32 accumulation "

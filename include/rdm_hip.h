@@ -127,8 +127,10 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores with float32 accumulation (error ~5e-6 of the result's maximum; the exact-f32
  * MFMA kernels: ~1e-6).  Gradients only - the forward pass never goes through these.  RDM_ERR_UNSUPPORTED for shapes without such a kernel
  * (1x1: 96 <= in_c <= 2304, in_c a multiple of 48; 3x3 / stride 1 / pad 1: out_c <= 48, rows of <= 93 pixels). */
+/* `products` (all four entry points): bf16 MFMAs per float32 product - 0 = the split arithmetic (3; 6 for the forward), 1 = operands simply ROUNDED to
+ * bf16 (one MFMA, float32 accumulation): the arithmetic of a mixed-precision (AMP) step, ~2e-3 of the result's maximum; RDM_NET_OPT_GEMM_BF16. */
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
-                        float* dw_packed, int32_t split_k, rdm_stream_t stream);
+                        float* dw_packed, int32_t split_k, int32_t products, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
  * sums when mask_x is given).  The workspace receives the split weights in MFMA-fragment order (re-formed on every call). */
 /* The dense layers' conv1 FORWARD (1x1 / stride 1; torchvision _DenseLayer.conv1 reached from network/RDM_Net.py:526-530) with a THREE-way split -
@@ -136,15 +138,15 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
  * parity): operands and meaning of rdm_conv2d_fwd without bias (BatchNorm + ReLU prologue on x, optional per-channel sums of y and y^2). */
 size_t rdm_conv1x1_fwd_x6_workspace_bytes(int32_t in_c, int32_t out_c);
 int rdm_conv1x1_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
-                       double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, rdm_stream_t stream);
+                       double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t products, rdm_stream_t stream);
 size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c);
 int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
                          int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,
-                         size_t workspace_bytes, rdm_stream_t stream);      /* 1x1 / stride 1 (the dense layers' conv1): w_packed = [out_c][in_c] */
+                         size_t workspace_bytes, int32_t products, rdm_stream_t stream);      /* 1x1 / stride 1 (the dense layers' conv1): w_packed = [out_c][in_c] */
 size_t rdm_conv3x3_dgrad_x3_workspace_bytes(int32_t in_c);
 int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w_packed, float* dx, int32_t dx_ld, const float* mask_x,
                          int32_t mask_ld, const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace,
-                         size_t workspace_bytes, rdm_stream_t stream);
+                         size_t workspace_bytes, int32_t products, rdm_stream_t stream);
 
 /* The 3x3 / stride 1 / pad 1 convolution with <= 48 outputs (torchvision _DenseLayer.conv2 reached from network/RDM_Net.py:144,526-530)
  * as Winograd F(2x2, 3x3) on the f32 MFMA path: 2.25x fewer multiply-adds than rdm_conv2d_fwd for the same result up to float32
@@ -296,9 +298,13 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                MFMA kernels: gradients agree to ~5e-6 of a tensor's maximum, the forward pass is untouched.  Ignored in
  *                                deterministic mode.
  *   RDM_NET_OPT_SPLIT_FWD        the 1x1 convolutions (conv1) of the dense blocks with >= 8 192 pixels run the three-way-split bf16x6 kernel
- *                                (rdm_conv1x1_fwd_x6) in rdm_net_forward: float32-equivalent accuracy, write-bound instead of f32-MFMA-bound. */
+ *                                (rdm_conv1x1_fwd_x6) in rdm_net_forward: float32-equivalent accuracy, write-bound instead of f32-MFMA-bound.
+ *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic: every launch that RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels
+ *                                rounds its operands to bf16 instead (ONE bf16 MFMA per product, float32 accumulation; activations, weights,
+ *                                BatchNorm statistics and the optimiser stay float32 in memory).  Not the parity configuration: tolerance stated in
+ *                                tests/test_gpu_mixed.py. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -40,13 +40,13 @@ _SIGNATURES = {
     "rdm_conv2d_fwd_bnsums": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_dgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_wgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
-    "rdm_conv2d_wgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
+    "rdm_conv2d_wgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, i32, vp]),
     "rdm_conv1x1_fwd_x6_workspace_bytes": (sz, [i32, i32]),
-    "rdm_conv1x1_fwd_x6": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "rdm_conv1x1_fwd_x6": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv1x1_dgrad_x3_workspace_bytes": (sz, [i32, i32]),
-    "rdm_conv1x1_dgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "rdm_conv1x1_dgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_dgrad_x3_workspace_bytes": (sz, [i32]),
-    "rdm_conv3x3_dgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "rdm_conv3x3_dgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_wino_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "rdm_conv3x3_wino_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_wino_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -207,11 +207,12 @@ size_t rdm_conv3x3_dgrad_x3_workspace_bytes(int32_t in_c) { return in_c > 0 && i
 
 int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
                          const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace, size_t workspace_bytes,
-                         rdm_stream_t stream) {
+                         int32_t products, rdm_stream_t stream) {
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
   RDM_CHECK_ARG(dy && w && dx, "conv3x3_dgrad_x3: NULL operand");
+  RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv3x3_dgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
   RDM_CHECK_ARG(!mask_x || (mask_scale && mask_shift && stat_a && stat_b), "conv3x3_dgrad_x3: mask needs scale, shift and both statistics");
   ConvGeom gd{d->batch, g.Ho, g.Wo, d->in_h, d->in_w, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, -1};
   FwdArgs a{};
@@ -220,17 +221,18 @@ int rdm_conv3x3_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
   if (!xs_dgrad3x3_supported(a)) { set_error("conv3x3_dgrad_x3: no split-precision kernel for this convolution (3x3 / stride 1 / pad 1, out_c = 48, in_c a multiple of 48, rows <= ~330 pixels)"); return RDM_ERR_UNSUPPORTED; }
-  return launch_xs_dgrad3x3(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
+  return launch_xs_dgrad3x3(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream, products == 1 ? 1 : 3);
 }
 
 size_t rdm_conv1x1_fwd_x6_workspace_bytes(int32_t in_c, int32_t out_c) { return out_c > 0 && in_c > 0 ? xs_fwd1x1_workspace_bytes(in_c, out_c) : 0; }
 
 int rdm_conv1x1_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y, double* stat_sum,
-                       double* stat_sq, void* workspace, size_t workspace_bytes, rdm_stream_t stream) {
+                       double* stat_sq, void* workspace, size_t workspace_bytes, int32_t products, rdm_stream_t stream) {
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
   RDM_CHECK_ARG(x && w && y, "conv1x1_fwd_x6: NULL operand");
+  RDM_CHECK_ARG(products == 0 || products == 1 || products == 6, "conv1x1_fwd_x6: products (%d) must be 0 / 6 (three-way split) or 1 (bf16 operands)", (int)products);
   RDM_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "conv1x1_fwd_x6: both statistics or none");
   FwdArgs a{};
   a.g = g; a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift;
@@ -238,18 +240,19 @@ int rdm_conv1x1_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w, c
   a.out = y; a.ldc = d->out_ld; a.M = d->batch * g.Ho * g.Wo; a.N = d->out_c;
   a.stat0 = stat_sum; a.stat1 = stat_sq;
   if (!xs_fwd1x1_supported(a)) { set_error("conv1x1_fwd_x6: no split-precision kernel for this convolution (1x1 / stride 1, out_c a multiple of 16, in_c of 4)"); return RDM_ERR_UNSUPPORTED; }
-  return launch_xs_fwd1x1(a, stat_sum ? EPI_STORE_STATS : EPI_STORE, workspace, workspace_bytes, stream);
+  return launch_xs_fwd1x1(a, stat_sum ? EPI_STORE_STATS : EPI_STORE, workspace, workspace_bytes, stream, products == 1 ? 1 : 6);
 }
 
 size_t rdm_conv1x1_dgrad_x3_workspace_bytes(int32_t out_c, int32_t in_c) { return out_c > 0 && in_c > 0 ? xs_dgrad1x1_workspace_bytes(out_c, in_c) : 0; }
 
 int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
                          const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, void* workspace, size_t workspace_bytes,
-                         rdm_stream_t stream) {
+                         int32_t products, rdm_stream_t stream) {
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
   RDM_CHECK_ARG(dy && w && dx, "conv1x1_dgrad_x3: NULL operand");
+  RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv1x1_dgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
   RDM_CHECK_ARG(!mask_x || (mask_scale && mask_shift && stat_a && stat_b), "conv1x1_dgrad_x3: mask needs scale, shift and both statistics");
   ConvGeom gd{d->batch, g.Ho, g.Wo, d->in_h, d->in_w, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, -1};
   FwdArgs a{};
@@ -258,12 +261,13 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
   if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 2304)"); return RDM_ERR_UNSUPPORTED; }
-  return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream);
+  return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream, products == 1 ? 1 : 3);
 }
 
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
-                        int32_t split_k, rdm_stream_t stream) {
+                        int32_t split_k, int32_t products, rdm_stream_t stream) {
   RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad_x3: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
+  RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv2d_wgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
@@ -274,7 +278,7 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
   a.Xs = x; a.ldx = d->in_ld; a.C = d->in_c; a.x_scale = bn_scale; a.x_shift = bn_shift;
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.split_k = split_k;
-  a.xsplit = 1;
+  a.xsplit = products == 1 ? 1 : 3;
   if (d->kh == 1 && d->kw == 1) return launch_xs_wgrad1x1(a, stream);
   if (d->kh == 3 && d->kw == 3) return launch_xs_wgrad3x3(a, stream);
   set_error("conv2d_wgrad_x3: no split-precision kernel for a %dx%d convolution", d->kh, d->kw);

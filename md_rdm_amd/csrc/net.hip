@@ -195,6 +195,8 @@ struct NetImpl {
   // the decoder (1 280 pixels) loses overall (53.3 vs 52.6 ms per step)
   int xs_min_pixels = 4096;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
+  int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
+  int xs_np() const { return (opt_gemm_bf16 & 2) ? 1 : 3; }      // value bits: 1 = the forward GEMMs, 2 = the gradient GEMMs (3 = both)
   int opt_split_fwd = 0;       // RDM_NET_OPT_SPLIT_FWD: conv1 of the many-pixel blocks on the three-way-split bf16x6 forward kernel
   int xf_min_pixels = 8192;
   bool xf_block(int b) const { return opt_split_fwd && !opt_det && bg[b].M >= xf_min_pixels; }
@@ -416,7 +418,7 @@ int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, b
     a.a_sum = bst + c_lo; a.a_sq = bst + g.ctot + c_lo; a.a_gamma = F(T, L.bn1.w) + c_lo; a.a_beta = F(T, L.bn1.b) + c_lo; a.a_count = (double)g.M;
   }
   if (n.xf_block(b) && !accumulate && !add_out && !raw_bn && xs_fwd1x1_supported(a))
-    return launch_xs_fwd1x1(a, fuse ? EPI_STORE_STATS : EPI_STORE, at<unsigned char>(ws, n.xfW), n.xfWBytes, s);
+    return launch_xs_fwd1x1(a, fuse ? EPI_STORE_STATS : EPI_STORE, at<unsigned char>(ws, n.xfW), n.xfWBytes, s, (n.opt_gemm_bf16 & 1) ? 1 : 6);
   const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
   return rc < 0 ? rc : 0;
 }
@@ -598,7 +600,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       WgradArgs xw{};
       xw.g = geom3x3(n.B, g.H, g.W, 1);
       xw.G = go; xw.ldg = g.ctot; xw.N = GROWTH; xw.Xs = Y; xw.ldx = cb; xw.C = cb; xw.x_scale = bn2; xw.x_shift = bn2 + cb;
-      xw.dW = dW3; xw.wtap = (long)GROWTH * cb; xw.ldw = cb; xw.xsplit = 1;
+      xw.dW = dW3; xw.wtap = (long)GROWTH * cb; xw.ldw = cb; xw.xsplit = n.xs_np();
       if (n.xs_block_wgrad3(b) && xs_wgrad3x3_supported(xw)) {
         // split-precision direct kernel: accumulates with f32 atomics into the zeroed gradient
         if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
@@ -633,7 +635,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
     if (n.xs_block(b) && xs_dgrad3x3_supported(d)) {
-      if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s))) return rc;
+      if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
     } else if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
     // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
     // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
@@ -652,7 +654,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       w.G = dZ; w.ldg = cb; w.N = cb;
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
-      w.xsplit = n.xs_block(b);
+      w.xsplit = n.xs_block(b) ? n.xs_np() : 0;
       if ((rc = launch_conv_wgrad(w, side))) return rc;
       RDM_HIP_OK(hipEventRecord(n.ev_dz[par], side));
       n.dz_busy[par] = true;
@@ -667,7 +669,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
     if (n.xs_block(b) && xs_dgrad1x1_supported(e)) {
-      if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s))) return rc;
+      if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
     } else if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
     if ((rc = launch_bn_bwd_apply(G, g.ctot, dZ1, cin, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
                                   Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
@@ -766,6 +768,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
   else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
+  else if (option == RDM_NET_OPT_GEMM_BF16) n->opt_gemm_bf16 = value == 1 ? 3 : value == 2 ? 1 : value == 3 ? 2 : 0;      // 1 = both, 2 = forward GEMMs only, 3 = gradient GEMMs only
   else if (option == RDM_NET_OPT_SPLIT_FWD) { n->opt_split_fwd = value != 0; if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = atoi(getenv("RDM_XF_MIN_PIXELS")); }
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;

@@ -127,7 +127,8 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
   long n_items;                               // set by the launcher: column tiles x row tiles x splits
   unsigned g_bytes, x_bytes;                  // set by the launcher: addressable extents of G / Xs
   int xcd_flat;                               // 1: keep the hardware block order (A/B switch)
-  int xsplit;                                 // 1: the split-precision (bf16x3) kernels of xsplit.hip may serve this launch (gradients only)
+  int xsplit;                                 // != 0: the kernels of xsplit.hip may serve this launch (gradients only): 3 (or any value but 1) = split precision,
+                                              // three bf16 MFMAs per product; 1 = operands rounded to bf16, one MFMA (the mixed-precision mode)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);

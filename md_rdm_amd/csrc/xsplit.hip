@@ -87,7 +87,7 @@ constexpr int XS_BM = 128, XS_BK = 32, XS_NTMAX = 12;
 constexpr int XS_A_IMG = XS_BK * XS_BM * 2;                 // one plane of the gradient tile: 8 KB
 constexpr int XS_B_IMG = XS_BK * XS_NTMAX * 16 * 2;         // one plane of the activation tile: <= 12 KB
 
-template <int NT>
+template <int NT, int NP>
 __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned char* smem, int c0, int n0, int s_begin, int s_end) {
   constexpr int BN = NT * 16;
   constexpr int BPATCH = 8 * NT;                            // 4-pixel x 16-channel patches of the activation tile
@@ -160,7 +160,7 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
       u32x2 hi, lo;
       split4(ra[it][0], ra[it][1], ra[it][2], ra[it][3], hi, lo);
       *reinterpret_cast<u32x2*>(Ahi + a_lds[it]) = hi;
-      *reinterpret_cast<u32x2*>(Alo + a_lds[it]) = lo;
+      if (NP == 3) *reinterpret_cast<u32x2*>(Alo + a_lds[it]) = lo;
     }
 #pragma unroll
     for (int it = 0; it < BL; ++it) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
       u32x2 hi, lo;
       split4(v[0], v[1], v[2], v[3], hi, lo);
       *reinterpret_cast<u32x2*>(Bhi + b_lds[it]) = hi;
-      *reinterpret_cast<u32x2*>(Blo + b_lds[it]) = lo;
+      if (NP == 3) *reinterpret_cast<u32x2*>(Blo + b_lds[it]) = lo;
     }
   };
 
@@ -218,8 +218,10 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[cur], acc[i][t], 0, 0, 0);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[cur], acc[i][t], 0, 0, 0);
+        if (NP == 3) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[cur], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[cur], acc[i][t], 0, 0, 0);
+        }
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[cur], acc[i][t], 0, 0, 0);
       }
     }
@@ -244,6 +246,7 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
   }
 }
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void xs_wgrad1x1_kernel(XsWgradArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * XS_A_IMG + 2 * XS_B_IMG + 2 * XS_NTMAX * 16 * 4];
   // work item = (column tile, row tile, K split), column tile fastest; XCD x works through a contiguous range of items so that the
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad1x1_kernel(XsWgradArgs p) {
   if (s_begin >= s_end) return;
   const int c0 = p.ct_c0[ct], n0 = nt * XS_BM;
   switch (p.ct_nt[ct]) {
-    case 6: xs_wgrad1x1_body<6>(p, smem, c0, n0, s_begin, s_end); break;
-    case 9: xs_wgrad1x1_body<9>(p, smem, c0, n0, s_begin, s_end); break;
-    default: xs_wgrad1x1_body<12>(p, smem, c0, n0, s_begin, s_end); break;
+    case 6: xs_wgrad1x1_body<6, NP>(p, smem, c0, n0, s_begin, s_end); break;
+    case 9: xs_wgrad1x1_body<9, NP>(p, smem, c0, n0, s_begin, s_end); break;
+    default: xs_wgrad1x1_body<12, NP>(p, smem, c0, n0, s_begin, s_end); break;
   }
 }
 
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void k_xs_pack_w3_dgrad(const float* __restric
   *reinterpret_cast<u32x4*>(dst + 1024) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-template <bool MASK>
+template <bool MASK, int NP>
 __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char xs_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
             u32x2 hi, lo;
             split4(v[u][0], v[u][1], v[u][2], v[u][3], hi, lo);
             *reinterpret_cast<u32x2*>(Ahi + (slot + 1) * XD_SLOT + quad * 8) = hi;
-            *reinterpret_cast<u32x2*>(Alo + (slot + 1) * XD_SLOT + quad * 8) = lo;
+            if (NP == 3) *reinterpret_cast<u32x2*>(Alo + (slot + 1) * XD_SLOT + quad * 8) = lo;
           }
         }
       }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < (NP == 3 ? 2 : 1); ++pl)
           w[t][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(wv + (unsigned)((ct16 + t) * (XD_KSTEPS * 2048))), j * 2048 + pl * 1024, 0));
     };
     // (the hardware range check looks at the VECTOR offset: the tile index travels there, so a tile past Cb reads as zeros)
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
       const int tapj = (4 * j) / 6 + (((4 * j) % 6 == 4) ? hi2 : 0);      // == (4 j + g) / 6; 9 in the zero half-step -> never valid
       const int a = (base0 + i * (16 * XD_SLOT) + dj) & __builtin_amdgcn_sbfe(vm[i / 3], (unsigned)(tapj + 10 * (i % 3)), 1u);
       f[0] = *reinterpret_cast<const bf16x8*>(Ahi + a);
-      f[1] = *reinterpret_cast<const bf16x8*>(Alo + a);
+      if (NP == 3) f[1] = *reinterpret_cast<const bf16x8*>(Alo + a);
     };
     frag(0, 0, gq[0]);
 #pragma unroll
@@ -435,8 +438,10 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][1], gq[cur][0], acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][0], gq[cur][1], acc[i][t], 0, 0, 0);
+          if (NP == 3) {
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][1], gq[cur][0], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][0], gq[cur][1], acc[i][t], 0, 0, 0);
+          }
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j & 1][t][0], gq[cur][0], acc[i][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(256) void k_xs_pack_w1_dgrad(const float* __restric
   *reinterpret_cast<u32x4*>(dst + plane) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-template <bool MASK>
+template <bool MASK, int NP>
 __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char x1_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
         u32x2 hi, lo;
         split4(rg[u][0], rg[u][1], rg[u][2], rg[u][3], hi, lo);
         *reinterpret_cast<u32x2*>(st + g_lds[u]) = hi;
-        *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
+        if (NP == 3) *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
       }
     }
 #pragma unroll
@@ -637,8 +642,10 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
 #pragma unroll
         for (int i = 0; i < X1_MTW; ++i)
           if (i < npw) {
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[i], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[i], acc[i][t], 0, 0, 0);
+            if (NP == 3) {
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[i], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[i], acc[i][t], 0, 0, 0);
+            }
             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[i], acc[i][t], 0, 0, 0);
           }
       }
@@ -718,6 +725,7 @@ struct XsWgrad3Args {
   unsigned g_bytes, y_bytes;
 };
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[XW_LDS];
   unsigned char* const Yhi = smem;
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
       split4(v[0], v[1], v[2], v[3], hi, lo);
       const unsigned a = y_lds(s, it);
       *reinterpret_cast<u32x2*>(Yhi + a) = hi;
-      *reinterpret_cast<u32x2*>(Ylo + a) = lo;
+      if (NP == 3) *reinterpret_cast<u32x2*>(Ylo + a) = lo;
     }
   };
   // gradient slab: 24 patches (8 row groups x 3 sixteen-channel tiles): group grp takes patch grp, groups 0..7 also patch 16 + grp
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
         const int row = 4 * rg + kq, rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
         const unsigned a = (unsigned)(256 * (rb * 3 + ct) + 32 * pr + 8 * jq);
         *reinterpret_cast<u32x2*>(gb + a) = hi;
-        *reinterpret_cast<u32x2*>(gb + XW_GPLANE + a) = lo;
+        if (NP == 3) *reinterpret_cast<u32x2*>(gb + XW_GPLANE + a) = lo;
       }
     }
   };
@@ -859,8 +867,10 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
       const bf16x8 bh = y_frag(Yhi, soff, tap), bl = y_frag(Ylo, soff, tap);
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
-        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[tap][nt], 0, 0, 0);
-        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[tap][nt], 0, 0, 0);
+        if (NP == 3) {
+          acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[tap][nt], 0, 0, 0);
+          acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[tap][nt], 0, 0, 0);
+        }
         acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh, acc[tap][nt], 0, 0, 0);
       }
     }
@@ -945,7 +955,7 @@ __global__ __launch_bounds__(256) void k_xs_pack_w1_fwd(const float* __restrict_
   *reinterpret_cast<u32x4*>(dst + 2 * plane) = u32x4{a2[0], a2[1], b2[0], b2[1]};
 }
 
-template <bool STATS>
+template <bool STATS, int NP>
 __global__ __launch_bounds__(512, 2) void xs_fwd1x1_kernel(XsFwd1Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char xf_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1005,8 +1015,10 @@ __global__ __launch_bounds__(512, 2) void xs_fwd1x1_kernel(XsFwd1Args p) {
         u32x2 p0, p1, p2;
         split3x4(v, p0, p1, p2);
         *reinterpret_cast<u32x2*>(Xi + x_lds[u]) = p0;
-        *reinterpret_cast<u32x2*>(Xi + XF_X_IMG + x_lds[u]) = p1;
-        *reinterpret_cast<u32x2*>(Xi + 2 * XF_X_IMG + x_lds[u]) = p2;
+        if (NP == 6) {
+          *reinterpret_cast<u32x2*>(Xi + XF_X_IMG + x_lds[u]) = p1;
+          *reinterpret_cast<u32x2*>(Xi + 2 * XF_X_IMG + x_lds[u]) = p2;
+        }
       }
     }
 #pragma unroll
@@ -1045,11 +1057,13 @@ __global__ __launch_bounds__(512, 2) void xs_fwd1x1_kernel(XsFwd1Args p) {
 #pragma unroll
         for (int i = 0; i < XF_MTW; ++i)
           if (i < npw) {                                        // smallest terms first
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[i], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x0[i], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x2[i], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x0[i], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1[i], acc[i][t], 0, 0, 0);
+            if (NP == 6) {
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[i], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x0[i], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x2[i], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x0[i], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1[i], acc[i][t], 0, 0, 0);
+            }
             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0[i], acc[i][t], 0, 0, 0);
           }
       }
@@ -1120,8 +1134,9 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   k.split_k = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs / 2, 256 * 2);     // >= 32 slabs of 32 pixels per split
   if (k.split_k > kslabs) k.split_k = (int)kslabs;
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * a.C, 13);
-  RDM_CENSUS("xs_wgrad1x1_kernel/%s/%s", a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1");
-  hipLaunchKernelGGL(xs_wgrad1x1_kernel, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
+  RDM_CENSUS("xs_wgrad1x1_kernel/x%d/%s/%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1");
+  if (a.xsplit == 1) hipLaunchKernelGGL(xs_wgrad1x1_kernel<1>, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(xs_wgrad1x1_kernel<3>, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;
@@ -1141,7 +1156,7 @@ bool xs_dgrad3x3_supported(const FwdArgs& a) {
          a.N % 16 == 0 && a.N >= 16 && xs_dgrad3_lds_bytes(g.W) <= 156 * 1024 && (g.W + 2) * XD_SLOT < 32768 && a.bias == nullptr && !a.accumulate && !a.add_out;
 }
 
-int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
   RDM_CHECK_ARG(xs_dgrad3x3_supported(a), "split-precision 3x3 dgrad: needs a 3x3 / stride 1 / pad 1 convolution with 48 gradient channels, N (%d) a multiple of 16, W (%d) <= 339", a.N, a.g.W);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 3x3 dgrad: plain or gate + statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 3x3 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1169,15 +1184,14 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   const long items = (long)k.mtiles * k.ctiles;
   const long slots = 256L * (lds <= 80 * 1024 ? 2 : 1);
   void* prof = profile_begin(s, 2.0 * (double)M * Cb * 432.0, 14);
-  RDM_CENSUS("xs_dgrad3x3_kernel/%s", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  RDM_CENSUS("xs_dgrad3x3_kernel/x%d/%s", np == 1 ? 1 : 3, epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
   const dim3 grid((unsigned)std::min(items, slots));
-  if (epi == EPI_MASK_STATS) {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(xs_dgrad3x3_kernel<true>, grid, dim3(256), lds, s, k);
-  } else {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(xs_dgrad3x3_kernel<false>, grid, dim3(256), lds, s, k);
-  }
+#define RDM_XS_D3(MASK_, NP_) do { \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad3x3_kernel<MASK_, NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL((xs_dgrad3x3_kernel<MASK_, NP_>), grid, dim3(256), lds, s, k); } while (0)
+  if (epi == EPI_MASK_STATS) { if (np == 1) RDM_XS_D3(true, 1); else RDM_XS_D3(true, 3); }
+  else { if (np == 1) RDM_XS_D3(false, 1); else RDM_XS_D3(false, 3); }
+#undef RDM_XS_D3
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;
@@ -1191,7 +1205,7 @@ bool xs_dgrad1x1_supported(const FwdArgs& a) {
   return one && a.N % 16 == 0 && a.N >= 16 && a.N <= 12 * X1_BNMAX && a.C % 4 == 0 && a.C >= 32 && a.bias == nullptr && !a.accumulate && !a.add_out;
 }
 
-int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
   RDM_CHECK_ARG(xs_dgrad1x1_supported(a), "split-precision 1x1 dgrad: needs a 1x1 / stride 1 convolution, 16 <= N (%d) <= %d a multiple of 16, C (%d) a multiple of 4", a.N, 12 * X1_BNMAX, a.C);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 1x1 dgrad: plain or gate + statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1225,15 +1239,14 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
   k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad1x1_workspace_bytes(K, C); k.x_bytes = (unsigned)xb;
   void* prof = profile_begin(s, 2.0 * (double)M * C * K, 16);
-  RDM_CENSUS("xs_dgrad1x1_kernel/%s", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  RDM_CENSUS("xs_dgrad1x1_kernel/x%d/%s", np == 1 ? 1 : 3, epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
   const dim3 grid((unsigned)(k.mtiles * k.ctiles));
-  if (epi == EPI_MASK_STATS) {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS));
-    hipLaunchKernelGGL(xs_dgrad1x1_kernel<true>, grid, dim3(512), X1_LDS, s, k);
-  } else {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS));
-    hipLaunchKernelGGL(xs_dgrad1x1_kernel<false>, grid, dim3(512), X1_LDS, s, k);
-  }
+#define RDM_XS_D1(MASK_, NP_) do { \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<MASK_, NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS)); \
+    hipLaunchKernelGGL((xs_dgrad1x1_kernel<MASK_, NP_>), grid, dim3(512), X1_LDS, s, k); } while (0)
+  if (epi == EPI_MASK_STATS) { if (np == 1) RDM_XS_D1(true, 1); else RDM_XS_D1(true, 3); }
+  else { if (np == 1) RDM_XS_D1(false, 1); else RDM_XS_D1(false, 3); }
+#undef RDM_XS_D1
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;
@@ -1269,8 +1282,9 @@ int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
   k.split = best;
   k.g_bytes = (unsigned)gb; k.y_bytes = (unsigned)yb;
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * 9.0 * a.C, 15);
-  RDM_CENSUS("xs_wgrad3x3_kernel/%s", a.x_scale ? "bn1" : "bn0");
-  hipLaunchKernelGGL(xs_wgrad3x3_kernel, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
+  RDM_CENSUS("xs_wgrad3x3_kernel/x%d/%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0");
+  if (a.xsplit == 1) hipLaunchKernelGGL(xs_wgrad3x3_kernel<1>, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(xs_wgrad3x3_kernel<3>, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;
@@ -1284,7 +1298,7 @@ bool xs_fwd1x1_supported(const FwdArgs& a) {
   return one && a.N % 16 == 0 && a.N >= 16 && a.C % 4 == 0 && a.C >= 4 && a.bias == nullptr && !a.accumulate && !a.add_out && a.a_sum == nullptr;
 }
 
-int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
   RDM_CHECK_ARG(xs_fwd1x1_supported(a), "split-precision 1x1 forward: needs a 1x1 / stride 1 convolution, N (%d) a multiple of 16, C (%d) a multiple of 4, no bias / accumulation", a.N, a.C);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_STORE_STATS, "split-precision 1x1 forward: plain or statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 forward: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1313,15 +1327,14 @@ int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, 
   k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
   k.x_bytes = (unsigned)xb; k.w_bytes = (unsigned)xs_fwd1x1_workspace_bytes(K, N);
   void* prof = profile_begin(s, 2.0 * (double)M * N * K, 17);
-  RDM_CENSUS("xs_fwd1x1_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", epi == EPI_STORE_STATS ? "STORE_STATS" : "STORE");
+  RDM_CENSUS("xs_fwd1x1_kernel/x%d/%s/%s", np == 1 ? 1 : 6, a.a_scale ? "bn1" : "bn0", epi == EPI_STORE_STATS ? "STORE_STATS" : "STORE");
   const dim3 grid((unsigned)(k.mtiles * k.ctiles));
-  if (epi == EPI_STORE_STATS) {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS));
-    hipLaunchKernelGGL(xs_fwd1x1_kernel<true>, grid, dim3(512), XF_LDS, s, k);
-  } else {
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS));
-    hipLaunchKernelGGL(xs_fwd1x1_kernel<false>, grid, dim3(512), XF_LDS, s, k);
-  }
+#define RDM_XS_F1(STATS_, NP_) do { \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<STATS_, NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS)); \
+    hipLaunchKernelGGL((xs_fwd1x1_kernel<STATS_, NP_>), grid, dim3(512), XF_LDS, s, k); } while (0)
+  if (epi == EPI_STORE_STATS) { if (np == 1) RDM_XS_F1(true, 1); else RDM_XS_F1(true, 6); }
+  else { if (np == 1) RDM_XS_F1(false, 1); else RDM_XS_F1(false, 6); }
+#undef RDM_XS_F1
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;

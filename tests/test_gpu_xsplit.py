@@ -56,7 +56,7 @@ def test_xs_wgrad1x1_vs_float64(case):
     before = sum(v for k, v in _lib.census().items() if k.startswith("xs_wgrad1x1_kernel/"))
     for split in (0, 1, 5):
         dw = torch.zeros(N, Cc, device=dev)
-        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, stream()))
+        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, 0, stream()))
         err = rel(dw.cpu().double(), want)
         assert err < TOL, (split, err)
     assert sum(v for k, v in _lib.census().items() if k.startswith("xs_wgrad1x1_kernel/")) == before + 3
@@ -70,7 +70,7 @@ def test_xs_wgrad1x1_rejects_unsupported_shapes():
     dev = torch.device("cuda:0")
     t = torch.zeros(64, 64, device=dev)
     d = ConvDesc(1, 8, 8, 64, 64, 64, 64, 1, 1, 1, 1, 0, 0)            # C = 64: not a multiple of 48
-    assert L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(t), ptr(t), None, None, ptr(t), 0, stream()) < 0
+    assert L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(t), ptr(t), None, None, ptr(t), 0, 0, stream()) < 0
 
 
 def _ref3x3_dgrad(gy, w9):
@@ -119,14 +119,14 @@ def test_xs_dgrad3x3_vs_float64(case):
     wsb = L.rdm_conv3x3_dgrad_x3_workspace_bytes(Cb)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     dx = torch.full((M, Cb), float("nan"), device=dev)
-    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dx), Cb, None, 0, None, None, None, None, ptr(ws), wsb, stream()))
+    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dx), Cb, None, 0, None, None, None, None, ptr(ws), wsb, 0, stream()))
     err = rel(dx.cpu().double(), want)
     assert err < TOL, err
     # gated: dz = dx * (y * sc + sh > 0); sums of dz and dz * y per channel
     s0 = torch.zeros(Cb, dtype=torch.float64, device=dev)
     s1 = torch.zeros_like(s0)
     dz = torch.full((M, Cb), float("nan"), device=dev)
-    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dz), Cb, ptr(yg), Cb, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    check(L.rdm_conv3x3_dgrad_x3(C.byref(d), gptr, ptr(wg), ptr(dz), Cb, ptr(yg), Cb, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
     gate = (y * sc + sh) > 0
     wantz = want * gate
     assert rel(dz.cpu().double(), wantz) < TOL
@@ -165,13 +165,13 @@ def test_xs_dgrad1x1_vs_float64(case):
     wsb = L.rdm_conv1x1_dgrad_x3_workspace_bytes(K, N)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     dx = torch.full((M, N), float("nan"), device=dev)
-    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dx), N, None, 0, None, None, None, None, ptr(ws), wsb, stream()))
+    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dx), N, None, 0, None, None, None, None, ptr(ws), wsb, 0, stream()))
     err = rel(dx.cpu().double(), want)
     assert err < TOL, err
     s0 = torch.zeros(N, dtype=torch.float64, device=dev)
     s1 = torch.zeros_like(s0)
     dz = torch.full((M, N), float("nan"), device=dev)
-    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dz), N, ptr(xg), ldx, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(gyg), ptr(wg), ptr(dz), N, ptr(xg), ldx, ptr(scg), ptr(shg), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
     xin = x[:, :N]
     gate = torch.addcmul(sh, xin, sc) > 0
     wantz = want * gate
@@ -220,7 +220,7 @@ def test_xs_wgrad3x3_vs_float64(case):
     xg, gyg, scg, shg = x.to(dev), gyb.to(dev), sc.to(dev), sh.to(dev)
     for split in (0, 1, 3):
         dw = torch.zeros(9, N, Cc, device=dev)
-        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, stream()))
+        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, 0, stream()))
         err = rel(dw.cpu().double(), want)
         assert err < TOL, (split, err)
     _RAN.add(("xs_wgrad3x3", case))
@@ -262,7 +262,7 @@ def test_xs_fwd1x1_x6_vs_float64(case):
         ssum = torch.zeros(N, dtype=torch.float64, device=dev)
         ssq = torch.zeros_like(ssum)
         check(L.rdm_conv1x1_fwd_x6(C.byref(d), ptr(xg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(y),
-                                   ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), wsb, stream()))
+                                   ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), wsb, 0, stream()))
         err = rel(y.cpu().double(), want)
         assert err < 2e-6, err                       # float32-equivalent: an order of magnitude inside the f32 kernels' 2e-5 gate
         if stats:

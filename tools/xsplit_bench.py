@@ -35,7 +35,7 @@ def wg1(B, H, W, Cb, cin, ld):
     d = ConvDesc(B, H, W, cin, ld, Cb, Cb, 1, 1, 1, 1, 0, 0)
     dW = torch.zeros(Cb, cin, device=dev)
     def f32(): check(L.rdm_conv2d_wgrad(C.byref(d), ptr(dZ), ptr(X), ptr(sc), ptr(sh), ptr(dW), stream()))
-    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(dZ), ptr(X), ptr(sc), ptr(sh), ptr(dW), 0, stream()))
+    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(dZ), ptr(X), ptr(sc), ptr(sh), ptr(dW), 0, 0, stream()))
     # error vs float64 on a slice of the output rows (the full product is 2 x 69312 x 2736 x 336 flops in f64 on the GPU: fine)
     a = torch.relu(X[:, :cin].double() * sc.double() + sh.double())
     want = dZ.double().t() @ a
@@ -63,7 +63,7 @@ def dg3(B, H, W, Cb):
     wsb = L.rdm_conv3x3_dgrad_x3_workspace_bytes(Cb)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     def f32(): check(L.rdm_conv2d_dgrad(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), stream()))
-    def x3(): check(L.rdm_conv3x3_dgrad_x3(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    def x3(): check(L.rdm_conv3x3_dgrad_x3(C.byref(d3), ptr(g48), ptr(w3), ptr(dZ), Cb, ptr(Y), Cb, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
     outs = {}
     for k, fn in (("f32", f32), ("x3", x3)):
         fn(); torch.cuda.synchronize(); outs[k] = dZ[:4096].clone()
@@ -87,7 +87,7 @@ def dg1(B, H, W, Cb, cin, ld):
     wsb = L.rdm_conv1x1_dgrad_x3_workspace_bytes(Cb, cin)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     def f32(): check(L.rdm_conv2d_dgrad(C.byref(d), ptr(dZ), ptr(w1), ptr(dX), cin, ptr(X), ld, ptr(sc), ptr(sh), ptr(s0), ptr(s1), stream()))
-    def x3(): check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(dZ), ptr(w1), ptr(dX), cin, ptr(X), ld, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    def x3(): check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(dZ), ptr(w1), ptr(dX), cin, ptr(X), ld, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
     outs = {}
     for k, fn in (("f32", f32), ("x3", x3)):
         fn(); torch.cuda.synchronize(); outs[k] = dX[:4096].clone()
@@ -108,8 +108,8 @@ def wg3(B, H, W, Cb):
     dW = torch.zeros(9, 48, Cb, device=dev)
     wsb = L.rdm_conv3x3_wino_wgrad_workspace_bytes(Cb, B, H, W)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    def f32(): check(L.rdm_conv3x3_wino_wgrad(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), ptr(ws), wsb, stream()))
-    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), 0, stream()))
+    def f32(): check(L.rdm_conv3x3_wino_wgrad(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), ptr(ws), wsb, 0, stream()))
+    def x3(): check(L.rdm_conv2d_wgrad_x3(C.byref(d3), ptr(g48), ptr(Y), ptr(sc), ptr(sh), ptr(dW), 0, 0, stream()))
     outs = {}
     for k, fn in (("f32", f32), ("x3", x3)):
         dW.zero_(); fn(); torch.cuda.synchronize(); outs[k] = dW.clone()
@@ -132,7 +132,7 @@ def fw1(B, H, W, Cb, cin, ld):
     wsb = L.rdm_conv1x1_fwd_x6_workspace_bytes(cin, Cb)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     def f32(): check(L.rdm_conv2d_fwd(C.byref(d), ptr(X), ptr(w1), None, ptr(sc), ptr(sh), ptr(Y), ptr(s0), ptr(s1), stream()))
-    def x6(): check(L.rdm_conv1x1_fwd_x6(C.byref(d), ptr(X), ptr(w1), ptr(sc), ptr(sh), ptr(Y), ptr(s0), ptr(s1), ptr(ws), wsb, stream()))
+    def x6(): check(L.rdm_conv1x1_fwd_x6(C.byref(d), ptr(X), ptr(w1), ptr(sc), ptr(sh), ptr(Y), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
     a = torch.relu(X[:8192, :cin].double() * sc.double() + sh.double())
     want = a @ w1.double().t()
     errs = {}
