@@ -14,6 +14,7 @@
 //    reference's memory_efficient recomputation.
 #include <stdlib.h>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "rdm_common.h"
@@ -137,6 +138,27 @@ struct BlockGeom { int H, W, M, ctot, cb; };
 
 }  // namespace
 
+// The weight-gradient stream is ONE per device for the whole process, shared by every plan: the runtime maps streams onto a handful of hardware
+// queues round-robin, and with a stream per plan the FOURTH plan of a process got the hardware queue of the caller's stream - its weight
+// gradients then ran in series with the dgrad chain (71 ms instead of 52 ms per step, measured) although nothing in the program had changed.
+static hipStream_t shared_side_stream(bool default_priority) {
+  static std::mutex mu;
+  static hipStream_t streams[2][64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  hipStream_t& s = streams[default_priority ? 1 : 0][dev];
+  if (!s) {
+    // lowest priority: the side stream carries bulk work (weight gradients) that should fill what the dependent chain on the
+    // caller's stream leaves free, not compete with it for workgroup slots
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = default_priority ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking) : hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_least);
+    if (e != hipSuccess) { set_error("side stream: %s", hipGetErrorString(e)); s = nullptr; }
+  }
+  return s;
+}
+
 struct NetImpl {
   int B, H0, W0, H1, W1;
   BlockGeom bg[4];
@@ -154,12 +176,8 @@ struct NetImpl {
   bool dz_busy[2] = {false, false};
   int ensure_side() {
     if (side) return 0;
-    // lowest priority: the side stream carries bulk work (weight gradients) that should fill what the dependent chain on the
-    // caller's stream leaves free, not compete with it for workgroup slots
-    int prio_least = 0, prio_greatest = 0;
-    RDM_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    if (g_variant == 14) RDM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    else RDM_HIP_OK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
+    side = shared_side_stream(g_variant == 14);
+    if (!side) return RDM_ERR_HIP;
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dy, hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[0], hipEventDisableTiming));
@@ -172,7 +190,7 @@ struct NetImpl {
     return 0;
   }
   ~NetImpl() {
-    if (side) { hipStreamDestroy(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
+    if (side) { hipStreamSynchronize(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
   }
   // Winograd F(2x2, 3x3) for the 3x3 convs of the blocks with many pixels (wino.hip): transformed weights per layer (formed on the side
   // stream at the start of forward) and one scratch for the per-split partial outputs
