@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
 //  * a wave owns one 16-channel tile: 9 taps x 3 gradient tiles = 27 accumulator tiles (108 registers), 81 MFMAs per slab.
 //  * K split over the slabs; partial sums leave with f32 atomics into the (pre-zeroed) packed gradient.
 // =============================================================================================
-constexpr int XW_RING = 256, XW_BC = 64, XW_YPLANE = XW_RING * XW_BC * 2, XW_GPLANE = 32 * 48 * 2;      // 32 KB, 3 KB
+constexpr int XW_D = 1, XW_RING = 256, XW_BC = 64, XW_YPLANE = XW_RING * XW_BC * 2, XW_GPLANE = 32 * 48 * 2;      // 32 KB, 3 KB
 constexpr int XW_LDS = 2 * XW_YPLANE + 4 * XW_GPLANE;
 
 struct XsWgrad3Args {
@@ -760,22 +760,26 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
     const int rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
     return (unsigned)(256 * (rb * 4 + (grp & 3)) + 32 * pr + 8 * jq);
   };
-  f32x4 ry[2]; float yhi[2];
-  auto load_y = [&](int s) {
+  // global loads run XW_D slabs ahead of their LDS stores (a slab's 81 MFMAs last ~0.5 us, a load under the step's traffic 2 - 3 us: with ONE
+  // slab of lead - the first form of this kernel - every barrier waited for memory and the matrix pipe ran at 12 % of its peak): XW_D register
+  // sets, target slab t in set (t - s_begin) % XW_D, indexed statically by the XW_D-fold unrolled slab loop
+  f32x4 ry[XW_D][2]; unsigned yin = 0u;                       // bit 2 set + it: that load was inside the image (ReLU upper bound inf; 0 zeroes a border position after BatchNorm)
+  auto load_y = [&](int set, int s) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const unsigned off = pix_off(s * 32 + 4 * ((grp >> 2) + 4 * it) + kq, p.ldy, yc, ycok);
-      ry[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdY, (int)off, 0, 0));
-      yhi[it] = off != XOOB ? __builtin_inff() : 0.f;        // ReLU upper bound: 0 zeroes a border position after BatchNorm
+      ry[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdY, (int)off, 0, 0));
+      yin = (yin & ~(1u << (2 * set + it))) | (off != XOOB ? 1u << (2 * set + it) : 0u);
     }
   };
-  auto store_y = [&](int s) {
+  auto store_y = [&](int set, int s) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      f32x4 v = ry[it];
+      f32x4 v = ry[set][it];
       if (bnrelu) {
+        const float top = (yin >> (2 * set + it)) & 1u ? __builtin_inff() : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], ysc[e], ysh[e]), 0.f, yhi[it]);
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], ysc[e], ysh[e]), 0.f, top);
       }
       u32x2 hi, lo;
       split4(v[0], v[1], v[2], v[3], hi, lo);
@@ -785,23 +789,23 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
     }
   };
   // gradient slab: 24 patches (8 row groups x 3 sixteen-channel tiles): group grp takes patch grp, groups 0..7 also patch 16 + grp
-  f32x4 rgv[2];
-  auto load_g = [&](int s) {
+  f32x4 rgv[XW_D][2];
+  auto load_g = [&](int set, int s) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
       const unsigned off = pi < 24 ? pix_off(s * 32 + 4 * rg + kq, p.ldg, 16 * ct + 4 * jq, 16 * ct + 4 * jq < p.N) : XOOB;
-      rgv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)off, 0, 0));
+      rgv[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)off, 0, 0));
     }
   };
-  auto store_g = [&](int s) {
+  auto store_g = [&](int set, int s) {
     unsigned char* const gb = Gb + (s & 1) * (2 * XW_GPLANE);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
       if (pi < 24) {
         u32x2 hi, lo;
-        split4(rgv[it][0], rgv[it][1], rgv[it][2], rgv[it][3], hi, lo);
+        split4(rgv[set][it][0], rgv[set][it][1], rgv[set][it][2], rgv[set][it][3], hi, lo);
         const int row = 4 * rg + kq, rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
         const unsigned a = (unsigned)(256 * (rb * 3 + ct) + 32 * pr + 8 * jq);
         *reinterpret_cast<u32x2*>(gb + a) = hi;
@@ -846,36 +850,51 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) acc[tap][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: activation slabs s_begin - ahead .. s_begin + ahead, gradient slab s_begin ----
-  for (int s = s_begin - p.ahead; s <= s_begin + p.ahead; ++s) { load_y(s); store_y(s); }
-  load_g(s_begin);
-  store_g(s_begin);
+  // ---- prologue: activation slabs s_begin - ahead .. s_begin + ahead (XW_D loads in flight at a time), gradient slab s_begin; then the loads of
+  // targets s_begin + 1 .. s_begin + XW_D - 1 are put in flight ----
+  for (int s = s_begin - p.ahead; s <= s_begin + p.ahead; s += XW_D) {
+#pragma unroll
+    for (int d = 0; d < XW_D; ++d) if (s + d <= s_begin + p.ahead) load_y(d, s + d);
+#pragma unroll
+    for (int d = 0; d < XW_D; ++d) if (s + d <= s_begin + p.ahead) store_y(d, s + d);
+  }
+  load_g(0, s_begin);
+  store_g(0, s_begin);
+#pragma unroll
+  for (int d = 1; d < XW_D; ++d) { load_y(d, s_begin + d + p.ahead); load_g(d, s_begin + d); }
   __syncthreads();
-  for (int s = s_begin; s < s_end; ++s) {
-    const bool more = s + 1 < s_end;
-    if (more) { load_y(s + 1 + p.ahead); load_g(s + 1); }     // in flight under this slab's MFMAs
-    const unsigned char* const gb = Gb + (s & 1) * (2 * XW_GPLANE);
-    bf16x8 ah[3], al[3];
+  for (int s0 = s_begin; s0 < s_end; s0 += XW_D) {
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-      ah[nt] = tr_frag(gb + frG0, gb + frG1, 256 * nt);
-      al[nt] = tr_frag(gb + XW_GPLANE + frG0, gb + XW_GPLANE + frG1, 256 * nt);
-    }
-    const unsigned soff = ((unsigned)s * 4096u) & (unsigned)(XW_YPLANE - 1);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const bf16x8 bh = y_frag(Yhi, soff, tap), bl = y_frag(Ylo, soff, tap);
+    for (int u = 0; u < XW_D; ++u) {
+      const int s = s0 + u;
+      if (s >= s_end) break;
+      // target s + XW_D (a slab past the end reads as zeros and is never stored) in flight under the MFMAs of XW_D slabs
+      load_y(u, s + XW_D + p.ahead); load_g(u, s + XW_D);
+      const bool more = s + 1 < s_end;
+      const unsigned char* const gb = Gb + (s & 1) * (2 * XW_GPLANE);
+      bf16x8 ah[3], al[3];
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
-        if (NP == 3) {
-          acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[tap][nt], 0, 0, 0);
-          acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[tap][nt], 0, 0, 0);
-        }
-        acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh, acc[tap][nt], 0, 0, 0);
+        ah[nt] = tr_frag(gb + frG0, gb + frG1, 256 * nt);
+        al[nt] = tr_frag(gb + XW_GPLANE + frG0, gb + XW_GPLANE + frG1, 256 * nt);
       }
+      const unsigned soff = ((unsigned)s * 4096u) & (unsigned)(XW_YPLANE - 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16x8 bh = y_frag(Yhi, soff, tap), bl = y_frag(Ylo, soff, tap);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          if (NP == 3) {
+            acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[nt], bh, acc[tap][nt], 0, 0, 0);
+            acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bl, acc[tap][nt], 0, 0, 0);
+          }
+          acc[tap][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[nt], bh, acc[tap][nt], 0, 0, 0);
+        }
+      }
+      // ring slot (s + 1 + ahead) & 7 and gradient buffer (s + 1) & 1: last read one slab ago
+      if (more) { store_y((u + 1) % XW_D, s + 1 + p.ahead); store_g((u + 1) % XW_D, s + 1); }
+      __syncthreads();
     }
-    if (more) { store_y(s + 1 + p.ahead); store_g(s + 1); }   // ring slot (s + 1 + ahead) & 7 and gradient buffer (s + 1) & 1: last read one slab ago
-    __syncthreads();
   }
 
   // ---- epilogue: D row = 4 g + r (n), column = l16 (c): f32 atomics into the packed gradient ----
