@@ -22,6 +22,12 @@ int rdm_microbench_mfma_staged_f32(float* scratch, int64_t scratch_floats, int32
 int rdm_microbench_gemm_dma_f32(const float* a, int32_t lda, const float* w, int32_t ldw, float* c, int32_t ldc, int32_t m, int32_t n, int32_t k,
                                 int32_t variant, rdm_stream_t stream);
 
+/* Per-XCD barrier + same-XCD hand-off probe (csrc/bench/xcd_sync.hip): `blocks` (<= 256) workgroups group themselves by the hardware XCC_ID, then run
+ * `rounds` rounds of {write payload_floats floats, drain, arrive on the XCD's counter, poll it with sc1 loads, read the right-hand neighbour's payload with
+ * sc1 loads, second barrier}.  state: 384 u32 (zeroed here); slots: 8 * 256 * payload_floats floats; result: 8 u32 per workgroup = xcc, rank, members of
+ * its XCD, values read that were not the round's, wall-clock ticks (100 MHz) and shader cycles of the rounds, timeout flag, 0.  Every wait is bounded. */
+int rdm_microbench_xcd_sync(uint32_t* state, float* slots, int32_t payload_floats, int32_t rounds, int32_t blocks, uint32_t* result, rdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,7 @@ _BENCH_SIGNATURES = {
     "rdm_microbench_mfma_f32": (C.c_int, [vp, i32, i32, vp]),
     "rdm_microbench_mfma_staged_f32": (C.c_int, [vp, i64, i32, i32, i32, i64, vp]),
     "rdm_microbench_gemm_dma_f32": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "rdm_microbench_xcd_sync": (C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
 }
 BENCH_LIB_PATH = os.path.join(_HERE, "librdm_bench.so")
 

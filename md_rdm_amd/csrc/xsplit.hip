@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
 //  * a wave owns one 16-channel tile: 9 taps x 3 gradient tiles = 27 accumulator tiles (108 registers), 81 MFMAs per slab.
 //  * K split over the slabs; partial sums leave with f32 atomics into the (pre-zeroed) packed gradient.
 // =============================================================================================
-constexpr int XW_D = 1, XW_RING = 256, XW_BC = 64, XW_YPLANE = XW_RING * XW_BC * 2, XW_GPLANE = 32 * 48 * 2;      // 32 KB, 3 KB
+constexpr int XW_D = 2, XW_RING = 256, XW_BC = 64, XW_YPLANE = XW_RING * XW_BC * 2, XW_GPLANE = 32 * 48 * 2;      // 32 KB, 3 KB
 constexpr int XW_LDS = 2 * XW_YPLANE + 4 * XW_GPLANE;
 
 struct XsWgrad3Args {
