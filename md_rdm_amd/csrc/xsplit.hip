@@ -515,9 +515,9 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
 //    The tile height (16 .. 320 pixels) is chosen by the host so that the grid fills whole rounds of the 256 CUs.
 //  * MFMA A operand = weights (rows = channels), B = gradient (columns = pixels): 16-byte gate loads / stores as in the 3x3 kernel.
 // =============================================================================================
-constexpr int X1_MTW = 5, X1_NTW = 6, X1_BMMAX = 4 * X1_MTW * 16, X1_BNMAX = 2 * X1_NTW * 16;
-constexpr int X1_G_IMG = X1_BMMAX * 64, X1_W_IMG = X1_BNMAX * 64;           // one plane of one stage
-constexpr int X1_STAGE = 2 * X1_G_IMG + 2 * X1_W_IMG, X1_LDS = 2 * X1_STAGE;
+constexpr int X1_MTW_BIG = 5, X1_MTW_SMALL = 2, X1_NTW = 6, X1_BNMAX = 2 * X1_NTW * 16;
+constexpr int X1_W_IMG = X1_BNMAX * 64;                                      // one plane of one stage
+constexpr int x1_lds(int mtw) { return 2 * (2 * (4 * mtw * 16 * 64) + 2 * X1_W_IMG); }
 
 struct XsDgrad1Args {
   const float* G; int ldg; int K;          // dY [M][ldg], K = Cb contracted channels
@@ -555,8 +555,14 @@ __global__ __launch_bounds__(256) void k_xs_pack_w1_dgrad(const float* __restric
   *reinterpret_cast<u32x4*>(dst + plane) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-template <bool MASK, int NP>
+// MTW = sixteen-pixel tiles per wave row (4 wave rows: tile heights up to 64 MTW pixels), D = k-steps the global loads run ahead of their LDS
+// stores.  (5, 1): the many-pixel blocks.  (2, 1): few pixels (dense_e4's 4 560: 128-pixel tiles; 164 instead of 230 registers).  D = 3 on the
+// small tile was built to cover the ~2 us load latency of a 0.24 us k-step (36 MFMAs) and measured SLOWER (dense_e4, C = 2064: 91 vs 63 us alone,
+// 51.6 vs 51.2 ms per step): hipcc's waitcnt insertion drains the queue to 3 outstanding loads at the head of every third unrolled step
+// (s_waitcnt vmcnt(3) in front of the first set's loads), so the lead is lost again - a hand-placed vmcnt is what it would take.
+template <bool MASK, int NP, int MTW, int D>
 __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
+  constexpr int X1_MTW = MTW, X1_G_IMG = 4 * MTW * 16 * 64, X1_STAGE = 2 * X1_G_IMG + 2 * X1_W_IMG;
   extern __shared__ __attribute__((aligned(1024))) unsigned char x1_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, g = lane >> 4;
@@ -585,23 +591,23 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
   }
   const int wpieces = BN * 8;                                  // 16-byte pieces of the weight slab: both planes
   const unsigned w_plane = (unsigned)p.ksteps * (unsigned)p.C * 64u;
-  f32x4 rg[X1_MTW]; u32x4 rw[3];
-  auto load_slab = [&](int j) {
+  f32x4 rg[D][X1_MTW]; u32x4 rw[D][3];                          // register set (k-step) % D
+  auto load_slab = [&](int set, int j) {                        // a k-step past the end reads as zeros (k >= K; weight offsets past the packed buffer)
 #pragma unroll
     for (int u = 0; u < X1_MTW; ++u)
-      rg[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
+      rg[set][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int q = tid + 512 * u, pl = q >= BN * 4, r = pl ? q - BN * 4 : q;      // piece r of plane pl: row r >> 2, chunk r & 3 (already swizzled in memory)
-      rw[u] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)(q < wpieces ? (unsigned)pl * w_plane + ((unsigned)j * (unsigned)p.C + (unsigned)(ct0 * 16)) * 64u + (unsigned)r * 16u : XOOB), 0, 0);
+      rw[set][u] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)((q < wpieces && j < p.ksteps) ? (unsigned)pl * w_plane + ((unsigned)j * (unsigned)p.C + (unsigned)(ct0 * 16)) * 64u + (unsigned)r * 16u : XOOB), 0, 0);
     }
   };
-  auto store_slab = [&](unsigned char* st) {
+  auto store_slab = [&](int set, unsigned char* st) {
 #pragma unroll
     for (int u = 0; u < X1_MTW; ++u) {
       if ((tid + 512 * u) >> 3 < BM) {
         u32x2 hi, lo;
-        split4(rg[u][0], rg[u][1], rg[u][2], rg[u][3], hi, lo);
+        split4(rg[set][u][0], rg[set][u][1], rg[set][u][2], rg[set][u][3], hi, lo);
         *reinterpret_cast<u32x2*>(st + g_lds[u]) = hi;
         if (NP == 3) *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
       }
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int q = tid + 512 * u, pl = q >= BN * 4, r = pl ? q - BN * 4 : q;
-      if (q < wpieces) *reinterpret_cast<u32x4*>(st + 2 * X1_G_IMG + pl * X1_W_IMG + r * 16) = rw[u];
+      if (q < wpieces) *reinterpret_cast<u32x4*>(st + 2 * X1_G_IMG + pl * X1_W_IMG + r * 16) = rw[set][u];
     }
   };
 
@@ -620,37 +626,44 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
     for (int t = 0; t < X1_NTW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned fr = (unsigned)(l16 * 64 + ((g ^ (((l16 >> 2) & 1) << 1)) * 16));      // fragment offset inside a 16-row tile of either image
 
-  load_slab(0);
-  store_slab(x1_smem);
+  load_slab(0, 0);
+  store_slab(0, x1_smem);
+#pragma unroll
+  for (int d = 1; d < D; ++d) load_slab(d, d);                 // k-steps 1 .. D - 1 in flight
   __syncthreads();
-  for (int j = 0; j < p.ksteps; ++j) {
-    const bool more = j + 1 < p.ksteps;
-    const unsigned char* const st = x1_smem + (j & 1) * X1_STAGE;
-    if (more) load_slab(j + 1);                                // in flight under this slab's MFMAs
-    bf16x8 gh[X1_MTW], gl[X1_MTW];
+  for (int j0 = 0; j0 < p.ksteps; j0 += D) {
 #pragma unroll
-    for (int i = 0; i < X1_MTW; ++i)
-      if (i < npw) {
-        gh[i] = *reinterpret_cast<const bf16x8*>(st + (pw0 + i) * 1024 + fr);
-        gl[i] = *reinterpret_cast<const bf16x8*>(st + X1_G_IMG + (pw0 + i) * 1024 + fr);
-      }
+    for (int u = 0; u < D; ++u) {
+      const int j = j0 + u;
+      if (j >= p.ksteps) break;
+      const bool more = j + 1 < p.ksteps;
+      const unsigned char* const st = x1_smem + (j & 1) * X1_STAGE;
+      load_slab(u, j + D);                                      // in flight under D k-steps of MFMAs (set u held k-step j: stored one step ago)
+      bf16x8 gh[X1_MTW], gl[X1_MTW];
 #pragma unroll
-    for (int t = 0; t < X1_NTW; ++t)
-      if (t < ntw) {
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + (tw0 + t) * 1024 + fr);
-        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + X1_W_IMG + (tw0 + t) * 1024 + fr);
+      for (int i = 0; i < X1_MTW; ++i)
+        if (i < npw) {
+          gh[i] = *reinterpret_cast<const bf16x8*>(st + (pw0 + i) * 1024 + fr);
+          gl[i] = *reinterpret_cast<const bf16x8*>(st + X1_G_IMG + (pw0 + i) * 1024 + fr);
+        }
 #pragma unroll
-        for (int i = 0; i < X1_MTW; ++i)
-          if (i < npw) {
-            if (NP == 3) {
-              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[i], acc[i][t], 0, 0, 0);
-              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[i], acc[i][t], 0, 0, 0);
+      for (int t = 0; t < X1_NTW; ++t)
+        if (t < ntw) {
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + (tw0 + t) * 1024 + fr);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(st + 2 * X1_G_IMG + X1_W_IMG + (tw0 + t) * 1024 + fr);
+#pragma unroll
+          for (int i = 0; i < X1_MTW; ++i)
+            if (i < npw) {
+              if (NP == 3) {
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[i], acc[i][t], 0, 0, 0);
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[i], acc[i][t], 0, 0, 0);
+              }
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[i], acc[i][t], 0, 0, 0);
             }
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[i], acc[i][t], 0, 0, 0);
-          }
-      }
-    if (more) store_slab(x1_smem + ((j + 1) & 1) * X1_STAGE);   // the other stage: every wave left it at the previous barrier
-    __syncthreads();
+        }
+      if (more) store_slab((u + 1) % D, x1_smem + ((j + 1) & 1) * X1_STAGE);   // the other stage: every wave left it at the previous barrier
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: a lane owns channels c4 .. c4 + 3 (D rows 4 g + r) of pixel m (D column l16) ----
@@ -1150,7 +1163,13 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   }
   k.n_ctiles = nct;
   const long tiles = (long)nct * cdiv(a.N, XS_BM), kslabs = (M + XS_BK - 1) / XS_BK;
-  k.split_k = a.split_k > 0 ? a.split_k : pick_split_k(tiles, kslabs / 2, 256 * 2);     // >= 32 slabs of 32 pixels per split
+  // K split: ONE round of the 512 resident workgroups (2 per CU), at least 16 slabs of 32 pixels per split (the f32 atomics of a split's epilogue
+  // cost as much as ~8 slabs at dense_e4's widths).  Swept per shape (alone, us; auto = the generic pick_split_k this replaced): dense_e3 C = 480:
+  // 102 at 15 splits vs 148 auto; C = 720: 147 at 11 vs 170; dense_e4 C = 432 / 768 / 1248 / 1632: 41 / 55 / 66 / 73 at 8 vs 71 / 80 / 82 / 85;
+  // dense_e2 C = 96 / 192: 185 / 291 at 23 vs 206 / 302; a second round (24 splits of 22 tiles) costs 40 % at once
+  if (a.split_k > 0) k.split_k = a.split_k;
+  else if (tiles > 512) k.split_k = pick_split_k(tiles, kslabs / 2, 256 * 2);
+  else k.split_k = (int)std::max<long>(1, std::min<long>(512 / tiles, kslabs / 16));
   if (k.split_k > kslabs) k.split_k = (int)kslabs;
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * a.C, 13);
   RDM_CENSUS("xs_wgrad1x1_kernel/x%d/%s/%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1");
@@ -1248,9 +1267,12 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   int c0 = 0;
   for (int t = 0; t < ctiles; ++t) { k.ct_c0[t] = c0; k.ct_n[t] = nct / ctiles + (t < nct % ctiles ? 1 : 0); c0 += k.ct_n[t]; }
   k.ctiles = ctiles;
-  // tile height: one workgroup per CU; the cheapest (rounds of 256 workgroups x tile height) wins
+  // tile height: one workgroup per CU; the cheapest (rounds of 256 workgroups x tile height) wins.  Few pixels: the small-tile instantiation
+  // (<= 128 pixels, three k-steps of loads in flight)
+  const bool small = M <= 8192;
+  const int mtw = small ? X1_MTW_SMALL : X1_MTW_BIG;
   int best_pt = 1; long best_cost = -1;
-  for (int pt = 1; pt <= 4 * X1_MTW; ++pt) {
+  for (int pt = 1; pt <= 4 * mtw; ++pt) {
     const long items = (long)cdiv(M, 16 * pt) * ctiles, rounds = (items + 255) / 256;
     const long cost = rounds * (pt * 16 + 24);                  // + a fixed per-tile cost (prologue / epilogue) in pixel units
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pt = pt; }
@@ -1258,14 +1280,16 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
   k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad1x1_workspace_bytes(K, C); k.x_bytes = (unsigned)xb;
   void* prof = profile_begin(s, 2.0 * (double)M * C * K, 16);
-  RDM_CENSUS("xs_dgrad1x1_kernel/x%d/%s", np == 1 ? 1 : 3, epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  RDM_CENSUS("xs_dgrad1x1_kernel/x%d/%s/%s", np == 1 ? 1 : 3, small ? "px128" : "px320", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
   const dim3 grid((unsigned)(k.mtiles * k.ctiles));
-#define RDM_XS_D1(MASK_, NP_) do { \
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<MASK_, NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, X1_LDS)); \
-    hipLaunchKernelGGL((xs_dgrad1x1_kernel<MASK_, NP_>), grid, dim3(512), X1_LDS, s, k); } while (0)
+#define RDM_XS_D1B(MASK_, NP_, MTW_, D_) do { \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<MASK_, NP_, MTW_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, x1_lds(MTW_))); \
+    hipLaunchKernelGGL((xs_dgrad1x1_kernel<MASK_, NP_, MTW_, D_>), grid, dim3(512), x1_lds(MTW_), s, k); } while (0)
+#define RDM_XS_D1(MASK_, NP_) do { if (small) RDM_XS_D1B(MASK_, NP_, X1_MTW_SMALL, 1); else RDM_XS_D1B(MASK_, NP_, X1_MTW_BIG, 1); } while (0)
   if (epi == EPI_MASK_STATS) { if (np == 1) RDM_XS_D1(true, 1); else RDM_XS_D1(true, 3); }
   else { if (np == 1) RDM_XS_D1(false, 1); else RDM_XS_D1(false, 3); }
 #undef RDM_XS_D1
+#undef RDM_XS_D1B
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;
