@@ -17,7 +17,7 @@ int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const
                          float* Bc, float* Cc, float* dgamma, float* dbeta, int C, int training, hipStream_t s);
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
-                        int training, hipStream_t s);
+                        int training, hipStream_t s, bool bf16_rows = false);
 int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t s);
 int launch_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H, int W, int C, hipStream_t s);
 int launch_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const float* sc, const float* sh, int B, int H, int W, int C,

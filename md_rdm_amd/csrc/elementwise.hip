@@ -222,8 +222,12 @@ int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t 
 // x (1/count) instead of eight f64 divisions per thread, and half as many, longer workgroups.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
 
-template <bool ACC>
+// BF (mixed-precision arithmetic mode, RDM_NET_OPT_GEMM_BF16): dz and dst are bf16 rows (ldz / ldd in ELEMENTS of that type) - the consumers of dst
+// (the 1x1 dgrad / wgrad on bf16 operands) round it to bf16 anyway, so storing it as bf16 loses nothing and halves two of the three streams
+template <bool ACC, bool BF = false>
 __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0,
                                                          const double* s1, double inv_count, const float* gamma, const float* mean,
                                                          const float* rstd, float* dgamma, float* dbeta, int M, int C4, int rows_per_block,
@@ -258,10 +262,27 @@ __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, co
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
   const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
   // per-lane byte offsets of row (m0 + rsub); rows advance by 4 through the scalar offset.  All extents < 4 GiB (launcher).
-  const unsigned vz = ((unsigned)rsub * (unsigned)ldz + (unsigned)c) * 4u, vx = ((unsigned)rsub * (unsigned)ldx + (unsigned)c) * 4u,
-                 vd = ((unsigned)rsub * (unsigned)ldd + (unsigned)c) * 4u;
-  unsigned sz = (unsigned)m0 * (unsigned)ldz * 4u, sx = (unsigned)m0 * (unsigned)ldx * 4u, sd = (unsigned)m0 * (unsigned)ldd * 4u;
-  const unsigned dzs = (unsigned)ldz * 16u, dxs = (unsigned)ldx * 16u, dds = (unsigned)ldd * 16u;      // 4 rows
+  constexpr unsigned EZ = BF ? 2u : 4u;                                // bytes per element of dz / dst
+  const unsigned vz = ((unsigned)rsub * (unsigned)ldz + (unsigned)c) * EZ, vx = ((unsigned)rsub * (unsigned)ldx + (unsigned)c) * 4u,
+                 vd = ((unsigned)rsub * (unsigned)ldd + (unsigned)c) * EZ;
+  unsigned sz = (unsigned)m0 * (unsigned)ldz * EZ, sx = (unsigned)m0 * (unsigned)ldx * 4u, sd = (unsigned)m0 * (unsigned)ldd * EZ;
+  const unsigned dzs = (unsigned)ldz * 4u * EZ, dxs = (unsigned)ldx * 16u, dds = (unsigned)ldd * 4u * EZ;      // 4 rows
+  auto ldz4 = [&](int voff, unsigned soff) -> u32x4e {                // 4 values of dz as float bits
+    if constexpr (BF) {
+      const u32x2e h = __builtin_amdgcn_raw_buffer_load_b64(rz, voff, (int)soff, 0);
+      return u32x4e{h.x << 16, h.x & 0xFFFF0000u, h.y << 16, h.y & 0xFFFF0000u};
+    } else {
+      return __builtin_amdgcn_raw_buffer_load_b128(rz, voff, (int)soff, 0);
+    }
+  };
+  auto st4 = [&](u32x4e r, int voff, unsigned soff) {
+    if constexpr (BF) {
+      const bf16x2e lo = {(__bf16)__uint_as_float(r.x), (__bf16)__uint_as_float(r.y)}, hi = {(__bf16)__uint_as_float(r.z), (__bf16)__uint_as_float(r.w)};
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2e{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rd, voff, (int)soff, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(r, rd, voff, (int)soff, 0);
+    }
+  };
   auto one = [&](u32x4e z, u32x4e xv, u32x4e o) {
     f32x2 z0 = {__uint_as_float(z.x), __uint_as_float(z.y)}, z1 = {__uint_as_float(z.z), __uint_as_float(z.w)};
     f32x2 x0 = {__uint_as_float(xv.x), __uint_as_float(xv.y)}, x1 = {__uint_as_float(xv.z), __uint_as_float(xv.w)};
@@ -279,30 +300,32 @@ __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, co
     u32x4e z[4], xv[4], o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      z[k] = __builtin_amdgcn_raw_buffer_load_b128(rz, (int)vz, (int)(sz + k * dzs), 0);
+      z[k] = ldz4((int)vz, sz + k * dzs);
       xv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vx, (int)(sx + k * dxs), 0);
       if (ACC) o[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)vd, (int)(sd + k * dds), 0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b128(one(z[k], xv[k], o[k]), rd, (int)vd, (int)(sd + k * dds), 0);
+    for (int k = 0; k < 4; ++k) st4(one(z[k], xv[k], o[k]), (int)vd, sd + k * dds);
     sz += 4 * dzs; sx += 4 * dxs; sd += 4 * dds;
   }
   for (; m < m1; m += 4) {                                            // tail: rows >= m1 belong to the next workgroup (or do not exist)
     const bool ok = m + rsub < m1;
-    const u32x4e z = __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? (int)vz : -1, (int)sz, 0);
+    const u32x4e z = ldz4(ok ? (int)vz : -1, sz);
     const u32x4e xv = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (int)vx : -1, (int)sx, 0);
     u32x4e o = {0u, 0u, 0u, 0u};
     if (ACC) o = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (int)vd : -1, (int)sd, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(one(z, xv, o), rd, ok ? (int)vd : -1, (int)sd, 0);
+    st4(one(z, xv, o), ok ? (int)vd : -1, sd);
     sz += dzs; sx += dxs; sd += dds;
   }
 }
 
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
-                        int training, hipStream_t s) {
+                        int training, hipStream_t s, bool bf16_rows) {
   const int C4 = C / 4, gx = cdiv(C4, 64);
-  const long eb[3] = {((long)(M - 1) * ldd + C) * 4, ((long)(M - 1) * ldz + C) * 4, ((long)(M - 1) * ldx + C) * 4};
+  RDM_CHECK_ARG(!(bf16_rows && accumulate), "bn_bwd: bf16 rows are built for the plain (norm2) form");
+  const long ez = bf16_rows ? 2 : 4;
+  const long eb[3] = {((long)(M - 1) * ldd + C) * ez, ((long)(M - 1) * ldz + C) * ez, ((long)(M - 1) * ldx + C) * 4};
   if (eb[0] >= 0xFFFFFFFFL || eb[1] >= 0xFFFFFFFFL || eb[2] >= 0xFFFFFFFFL) {
     set_error("bn_bwd: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing");
     return RDM_ERR_UNSUPPORTED;
@@ -311,6 +334,7 @@ int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const flo
   rpb = std::max(16, (rpb + 15) / 16 * 16);
   dim3 grid(gx, cdiv(M, rpb));
   if (accumulate) hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
+  else if (bf16_rows) hipLaunchKernelGGL((k_bn_bwd_apply<false, true>), grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
   else hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
   RDM_LAUNCH_OK();
   return 0;

@@ -938,6 +938,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
 
 static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s) {
   FwdArgs a = a_in;
+  RDM_CHECK_ARG(!a.out_bf16 && !a.a_bf16, "conv: bf16 rows are read / written by the one-product kernels of xsplit.hip only");
   RDM_CHECK_ARG(a.C % 16 == 0 && a.C > 0, "conv: contracted channels (%d) must be a positive multiple of 16", a.C);
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldw % 4 == 0 && a.wtap % 4 == 0, "conv: strides must be multiples of 4 floats");
   RDM_CHECK_ARG(!b_kstrided || a.N % 4 == 0, "dgrad: N (%d) must be a multiple of 4", a.N);
@@ -1109,6 +1110,7 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
   // split-precision (bf16x3) kernel where the caller allows it: long contractions only (the plan's many-pixel blocks)
   if (a.xsplit && !t_deterministic && !taps && Mpix >= 1024 && xs_wgrad1x1_supported(a)) return launch_xs_wgrad1x1(a, s);
   if (a.xsplit && !t_deterministic && taps && Mpix >= 1024 && xs_wgrad3x3_supported(a)) return launch_xs_wgrad3x3(a, s);
+  RDM_CHECK_ARG(!a.g_bf16, "wgrad: bf16 gradient rows are read by the one-product 1x1 kernel of xsplit.hip only");
   const long kslabs = (Mpix + 15) / 16;
   const bool narrow = a.N <= 48;                      // 3x3 convs of the dense layers: 48 output channels
   // a ragged last column tile of the 128 x 96 config wastes up to 25 % of the MFMAs (C = 144: 2 x 96); 256 x 48 tiles fit every

@@ -652,13 +652,24 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     d.Wt = w2p; d.wtap = (long)GROWTH * cb; d.ldw = cb;
     d.out = dZ; d.ldc = cb; d.M = g.M; d.N = cb;
     d.stat0 = s0; d.stat1 = s1; d.X = Y; d.ldx = cb; d.x_scale = bn2; d.x_shift = bn2 + cb;
+    // mixed-precision arithmetic on the gradient GEMMs (RDM_NET_OPT_GEMM_BF16): when all three consumers / producers of the layer's dZ -> dY
+    // tensor are the one-product kernels, it LIVES as bf16 (they round it to bf16 at staging anyway): its four passes move half the bytes
+    bool dz_bf16 = false;
+    {
+      FwdArgs e1{};
+      e1.g = geom1x1(n.B, g.H, g.W); e1.C = cb; e1.N = cin; e1.M = g.M;
+      WgradArgs w1{};
+      w1.g = geom1x1(n.B, g.H, g.W); w1.N = cb; w1.C = cin;
+      dz_bf16 = n.xs_np() == 1 && n.xs_block(b) && xs_dgrad3x3_supported(d) && xs_dgrad1x1_supported(e1) && xs_wgrad1x1_supported(w1) && g.M >= 1024 && Gr[L.conv1] != nullptr;
+    }
+    d.out_bf16 = dz_bf16;
     if (n.xs_block(b) && xs_dgrad3x3_supported(d)) {
       if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
     } else if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
     // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
     // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
     if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,
-                                  Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s)))
+                                  Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s, dz_bf16)))
       return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
@@ -673,6 +684,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       w.Xs = blk; w.ldx = g.ctot; w.C = cin; w.x_scale = bn1; w.x_shift = bn1 + cin;
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
       w.xsplit = n.xs_block(b) ? n.xs_np() : 0;
+      w.g_bf16 = dz_bf16;
       if ((rc = launch_conv_wgrad(w, side))) return rc;
       RDM_HIP_OK(hipEventRecord(n.ev_dz[par], side));
       n.dz_busy[par] = true;
@@ -686,6 +698,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     e.Wt = F(T, L.conv1); e.wtap = 0; e.ldw = cin;
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
+    e.a_bf16 = dz_bf16;
     if (n.xs_block(b) && xs_dgrad1x1_supported(e)) {
       if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
     } else if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;

@@ -100,6 +100,9 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   // RAW BatchNorm prologue (training, few-pixel blocks): instead of finished (a_scale, a_shift) the kernel gets the channel sums and forms
   // the affine itself - the k_bn_finalize launch (5-9 us + a dependent-launch gap) leaves the critical chain; C <= RAWBN_MAX_C
   const double* a_sum; const double* a_sq; const float* a_gamma; const float* a_beta; double a_count;
+  // mixed-precision arithmetic mode, xsplit.hip kernels with one bf16 MFMA per product only: `out` (3x3 dgrad) / `A` (1x1 dgrad) are rows of bf16
+  // (ldc / lda in elements of that type)
+  int out_bf16, a_bf16;
 };
 constexpr int RAWBN_MAX_C = 768;
 
@@ -129,6 +132,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
   int xcd_flat;                               // 1: keep the hardware block order (A/B switch)
   int xsplit;                                 // != 0: the kernels of xsplit.hip may serve this launch (gradients only): 3 (or any value but 1) = split precision,
                                               // three bf16 MFMAs per product; 1 = operands rounded to bf16, one MFMA (the mixed-precision mode)
+  int g_bf16;                                 // xsplit == 1 only: G is rows of bf16 (ldg in elements of that type)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);

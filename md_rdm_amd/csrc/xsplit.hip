@@ -74,6 +74,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsi
 // ---------------------------------------------------------------------------------------------
 struct XsWgradArgs {
   const float* G; int ldg; int N;
+  int g_bf16;                   // NP == 1 only: G is rows of bf16 (ldg in elements)
   const float* X; int ldx; int C;
   const float* x_scale; const float* x_shift;
   float* dW; int ldw;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
     const int rg = (grp >> 3) + 2 * it, ct = grp & 7;
     const int row = 4 * rg + kq, n = n0 + 16 * ct + 4 * jq;
     a_row[it] = n < p.N ? row : 0x40000000;
-    a_voff[it] = (unsigned)row * (unsigned)(p.ldg * 4) + (unsigned)(n * 4);
+    a_voff[it] = (NP == 1 && p.g_bf16) ? (unsigned)row * (unsigned)(p.ldg * 2) + (unsigned)(n * 2) : (unsigned)row * (unsigned)(p.ldg * 4) + (unsigned)(n * 4);
     const int rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
     a_lds[it] = (unsigned)(256 * (rb * 8 + ct) + 32 * pr + 8 * jq);
   }
@@ -141,11 +142,16 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
   float bhi[BL];                                              // ReLU upper bound: +inf for a live element, 0 for a dead one (zeroes it after BatchNorm)
   auto load_slab = [&](int s) {
     const int m0 = s * XS_BK;
-    const unsigned sog = (unsigned)m0 * (unsigned)(p.ldg * 4), sox = (unsigned)m0 * (unsigned)(p.ldx * 4);
+    const unsigned sog = (unsigned)m0 * (unsigned)(p.ldg * ((NP == 1 && p.g_bf16) ? 2 : 4)), sox = (unsigned)m0 * (unsigned)(p.ldx * 4);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const bool ok = m0 + a_row[it] < p.M;
-      ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)(ok ? a_voff[it] + sog : XOOB), 0, 0));
+      if (NP == 1 && p.g_bf16) {
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(srdG, (int)(ok ? a_voff[it] + sog : XOOB), 0, 0);
+        ra[it] = f32x4{__uint_as_float(h[0]), __uint_as_float(h[1]), 0.f, 0.f};
+      } else {
+        ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)(ok ? a_voff[it] + sog : XOOB), 0, 0));
+      }
     }
 #pragma unroll
     for (int it = 0; it < BL; ++it) {
@@ -158,7 +164,8 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       u32x2 hi, lo;
-      split4(ra[it][0], ra[it][1], ra[it][2], ra[it][3], hi, lo);
+      if (NP == 1 && p.g_bf16) hi = u32x2{__float_as_uint(ra[it][0]), __float_as_uint(ra[it][1])};
+      else split4(ra[it][0], ra[it][1], ra[it][2], ra[it][3], hi, lo);
       *reinterpret_cast<u32x2*>(Ahi + a_lds[it]) = hi;
       if (NP == 3) *reinterpret_cast<u32x2*>(Alo + a_lds[it]) = lo;
     }
@@ -246,6 +253,9 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
   }
 }
 
+// (a narrow instantiation - column tiles of <= 96 channels, 162 registers, three workgroups per CU - was measured against this one: 0.17 vs 0.19 ms
+// at dense_e2 C = 96 and 0.055 vs 0.071 at dense_e3 C = 192, but 0.29 vs 0.24 at C = 144 and 0.57 vs 0.52 at C = 336: occupancy is not what
+// holds the kernel; per 32-pixel slab its four waves read 112 KB of fragments from LDS for 1 152 MFMA cycles each - the LDS is as busy as the pipe)
 template <int NP>
 __global__ __launch_bounds__(256, 2) void xs_wgrad1x1_kernel(XsWgradArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * XS_A_IMG + 2 * XS_B_IMG + 2 * XS_NTMAX * 16 * 4];
@@ -298,6 +308,7 @@ struct XsDgrad3Args {
   const float* X; int ldx; const float* x_scale; const float* x_shift;
   double* stat0; double* stat1;
   int B, H, W, M, Cb;
+  int out_bf16;                            // NP == 1 only: `out` is rows of bf16 (ldc in elements): the consumers round to bf16 anyway
   int nslots, plane_bytes;                 // slot 0 = zeros, slot 1 + s = pixel m0 - (W + 1) + s, s < XD_BM + 2 (W + 1)
   int mtiles, ctiles;                      // pixel tiles, 128-channel column tiles
   unsigned g_bytes, w_bytes, x_bytes, o_bytes;
@@ -481,7 +492,10 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
           // (plain global stores ON PURPOSE: with buffer-form stores here, the shuffles and the exec-masked atomics of the statistics below
           // left wrong values in lanes 12-15 of some stored registers on MI355X / ROCm 7.2 - measured, cause not established; the same
           // epilogue with global_store_dwordx4 is exact)
-          if (ok) *reinterpret_cast<f32x4*>(p.out + (long)(m0 + i * 16 + l16) * p.ldc + c4) = v;
+          if (NP == 1 && p.out_bf16) {
+            const bf16x2 lo2 = {(__bf16)v[0], (__bf16)v[1]}, hi2 = {(__bf16)v[2], (__bf16)v[3]};
+            if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + (long)(m0 + i * 16 + l16) * p.ldc + c4) = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+          } else if (ok) *reinterpret_cast<f32x4*>(p.out + (long)(m0 + i * 16 + l16) * p.ldc + c4) = v;
         }
       }
       if (MASK) {
@@ -521,6 +535,7 @@ constexpr int x1_lds(int mtw) { return 2 * (2 * (4 * mtw * 16 * 64) + 2 * X1_W_I
 
 struct XsDgrad1Args {
   const float* G; int ldg; int K;          // dY [M][ldg], K = Cb contracted channels
+  int g_bf16;                              // NP == 1 only: dY is rows of bf16 (ldg in elements): staged verbatim, no conversion
   const unsigned char* Wp;                 // [plane][ksteps][C][64 B]
   float* out; int ldc;
   const float* X; int ldx; const float* x_scale; const float* x_shift;
@@ -586,7 +601,8 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
     const int idx = tid + 512 * u, row = idx >> 3, f4 = idx & 7;
     const bool ok = row < BM && m0 + row < p.M;
     g_k[u] = ok ? 4 * f4 : 0x40000000;
-    g_voff[u] = (unsigned)(m0 + row) * (unsigned)(p.ldg * 4) + (unsigned)(f4 * 16);
+    g_voff[u] = (NP == 1 && p.g_bf16) ? (unsigned)(m0 + row) * (unsigned)(p.ldg * 2) + (unsigned)(f4 * 8)
+                                      : (unsigned)(m0 + row) * (unsigned)(p.ldg * 4) + (unsigned)(f4 * 16);
     g_lds[u] = (unsigned)(row * 64 + (((f4 >> 1) ^ (((row >> 2) & 1) << 1)) * 16) + (f4 & 1) * 8);
   }
   const int wpieces = BN * 8;                                  // 16-byte pieces of the weight slab: both planes
@@ -594,8 +610,14 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
   f32x4 rg[D][X1_MTW]; u32x4 rw[D][3];                          // register set (k-step) % D
   auto load_slab = [&](int set, int j) {                        // a k-step past the end reads as zeros (k >= K; weight offsets past the packed buffer)
 #pragma unroll
-    for (int u = 0; u < X1_MTW; ++u)
-      rg[set][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
+    for (int u = 0; u < X1_MTW; ++u) {
+      if (NP == 1 && p.g_bf16) {                                // 4 bf16 = 8 bytes, kept in the first two registers of the set
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 64) : XOOB), 0, 0);
+        rg[set][u] = f32x4{__uint_as_float(h[0]), __uint_as_float(h[1]), 0.f, 0.f};
+      } else {
+        rg[set][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)((32 * j + g_k[u] < p.K) ? g_voff[u] + (unsigned)(j * 128) : XOOB), 0, 0));
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int q = tid + 512 * u, pl = q >= BN * 4, r = pl ? q - BN * 4 : q;      // piece r of plane pl: row r >> 2, chunk r & 3 (already swizzled in memory)
@@ -607,7 +629,8 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
     for (int u = 0; u < X1_MTW; ++u) {
       if ((tid + 512 * u) >> 3 < BM) {
         u32x2 hi, lo;
-        split4(rg[set][u][0], rg[set][u][1], rg[set][u][2], rg[set][u][3], hi, lo);
+        if (NP == 1 && p.g_bf16) hi = u32x2{__float_as_uint(rg[set][u][0]), __float_as_uint(rg[set][u][1])};
+        else split4(rg[set][u][0], rg[set][u][1], rg[set][u][2], rg[set][u][3], hi, lo);
         *reinterpret_cast<u32x2*>(st + g_lds[u]) = hi;
         if (NP == 3) *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
       }
@@ -1148,9 +1171,11 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   RDM_CHECK_ARG(xs_wgrad1x1_supported(a), "split-precision 1x1 wgrad: needs a 1x1 / stride 1 convolution with 96 <= C (%d) <= 2304, C a multiple of 48, N (%d) of 4", a.C, a.N);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0 && ((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "split-precision 1x1 wgrad: strides multiples of 4 floats, operands 16-byte aligned");
   const long M = (long)a.g.B * a.g.Ho * a.g.Wo;
-  const long gb = ((M - 1) * a.ldg + a.N) * 4, xb = ((M - 1) * a.ldx + a.C) * 4;
+  RDM_CHECK_ARG(!a.g_bf16 || a.xsplit == 1, "1x1 wgrad: bf16 gradient rows exist in the one-product (mixed-precision) form only");
+  const long gb = ((M - 1) * a.ldg + a.N) * (a.g_bf16 ? 2 : 4), xb = ((M - 1) * a.ldx + a.C) * 4;
   if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
   XsWgradArgs k{};
+  k.g_bf16 = a.g_bf16;
   k.G = a.G; k.ldg = a.ldg; k.N = a.N; k.X = a.Xs; k.ldx = a.ldx; k.C = a.C; k.x_scale = a.x_scale; k.x_shift = a.x_shift;
   k.dW = a.dW; k.ldw = a.ldw; k.M = (int)M; k.g_bytes = (unsigned)gb; k.x_bytes = (unsigned)xb;
   // column tiles of 192 / 144 / 96 channels: the C / 48 units are dealt as evenly as possible over ceil(units / 4) tiles
@@ -1212,6 +1237,8 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   XsDgrad3Args k{};
   k.G = a.A; k.ldg = a.lda; k.Wf = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
   k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
+  RDM_CHECK_ARG(!a.out_bf16 || np == 1, "3x3 dgrad: bf16 output rows exist in the one-product (mixed-precision) form only");
+  k.out_bf16 = a.out_bf16;
   k.B = a.g.B; k.H = a.g.H; k.W = a.g.W; k.M = (int)M; k.Cb = Cb;
   k.nslots = 1 + XD_BM + 2 * (a.g.W + 1);
   k.plane_bytes = (k.nslots * XD_SLOT + 1023) & ~1023;
@@ -1251,7 +1278,8 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   const int K = a.C, C = a.N, ksteps = (K + 31) / 32;
   RDM_CHECK_ARG(ws != nullptr && ((uintptr_t)ws & 15) == 0 && ws_bytes >= xs_dgrad1x1_workspace_bytes(K, C), "split-precision 1x1 dgrad: workspace too small or misaligned (%zu < %zu)", ws_bytes, xs_dgrad1x1_workspace_bytes(K, C));
   const long M = a.M;
-  const long gb = ((M - 1) * a.lda + K) * 4, xb = a.X ? ((M - 1) * a.ldx + C) * 4 : 16;
+  RDM_CHECK_ARG(!a.a_bf16 || np == 1, "1x1 dgrad: bf16 gradient rows exist in the one-product (mixed-precision) form only");
+  const long gb = ((M - 1) * a.lda + K) * (a.a_bf16 ? 2 : 4), xb = a.X ? ((M - 1) * a.ldx + C) * 4 : 16;
   if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 dgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
   {
     const long threads = (long)ksteps * 4 * C;
@@ -1259,7 +1287,7 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
     RDM_LAUNCH_OK();
   }
   XsDgrad1Args k{};
-  k.G = a.A; k.ldg = a.lda; k.K = K; k.Wp = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
+  k.G = a.A; k.ldg = a.lda; k.K = K; k.g_bf16 = a.a_bf16; k.Wp = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
   k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
   k.M = (int)M; k.C = C; k.ksteps = ksteps;
   // column tiles of <= 12 sixteen-channel tiles, as even as possible
