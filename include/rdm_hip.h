@@ -299,10 +299,12 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                deterministic mode.
  *   RDM_NET_OPT_SPLIT_FWD        the 1x1 convolutions (conv1) of the dense blocks with >= 8 192 pixels run the three-way-split bf16x6 kernel
  *                                (rdm_conv1x1_fwd_x6) in rdm_net_forward: float32-equivalent accuracy, write-bound instead of f32-MFMA-bound.
- *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic: every launch that RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels
- *                                rounds its operands to bf16 instead (ONE bf16 MFMA per product, float32 accumulation; activations, weights,
- *                                BatchNorm statistics and the optimiser stay float32 in memory).  Not the parity configuration: tolerance stated in
- *                                tests/test_gpu_mixed.py. */
+ *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic (the reference's default --precision 16, train.py:11,57-58): every launch that
+ *                                RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels rounds its operands to bf16 instead (ONE bf16
+ *                                MFMA per product, float32 accumulation).  value 1 = forward and gradient GEMMs, 2 = forward only, 3 = gradient GEMMs
+ *                                only, 0 = off.  Activations, weights, BatchNorm statistics and the optimiser stay float32 in memory; with the gradient
+ *                                GEMMs in this mode the per-layer dZ -> dY scratch tensor is kept as bf16.  Not the parity configuration: tolerance
+ *                                stated in tests/test_gpu_mixed.py. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
                               RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
