@@ -51,7 +51,8 @@ class ReduceLROnPlateau:
 def main(argv=None):
     parser = ArgumentParser("Trains mono depth estimation models (MI355X-native stack)")
     parser.add_argument("--seed", default=None, type=int)
-    parser.add_argument("--precision", default=32, type=int, help="32: exact-f32 MFMA training and validation; 16: f32 training with the VALIDATION forward on the bf16 MFMA path (the reference's AMP O2, train.py:57-58, has no bf16 backward counterpart here)")
+    parser.add_argument("--precision", default=32, type=int, help="32 (default here - the parity configuration): float32 training and validation; 16 (the reference's default, AMP O2, train.py:11,57-58): training in the mixed-precision "
+                        "arithmetic mode (model.gemm_bf16 = 1: bf16 GEMM operands with float32 accumulation in dense_e2 / e3 / e4, float32 weights, statistics and optimiser) and the VALIDATION forward on the bf16 MFMA path")
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--dev", action="store_true", help="one train + one val step (Lightning fast_dev_run)")
     parser.add_argument("--overfit", action="store_true", help="reuse one batch")
@@ -102,6 +103,7 @@ def main(argv=None):
     from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
     model = DepthEstimationNet(relative_decoders=tuple(args.relative_decoders)).to(dev)
+    model.gemm_bf16 = 1 if args.precision == 16 else 0         # --precision 16: mixed-precision arithmetic for the training step (tolerance: tests/test_gpu_mixed.py)
     resumed = None
     if args.resume:
         from .checkpoint import from_lightning

@@ -166,7 +166,7 @@ def test_train_script_flags_work_or_raise(capsys):
     finally:
         torch.autograd.set_detect_anomaly(False)
     assert "Enabling anomaly detection" in capsys.readouterr().out
-    # --precision 16: training stays f32, the validation forward runs on the bf16 MFMA path
+    # --precision 16: training in the mixed-precision arithmetic mode (bf16 GEMM operands), the validation forward on the bf16 MFMA path
     train.main(["--synthetic", "--dev", "--batch_size", "2", "--seed", "1", "--precision", "16"])
     out = capsys.readouterr().out
     assert "epoch 0 step 0 loss" in out and "val_delta1" in out and "nan" not in out.lower()
