@@ -572,9 +572,11 @@ __global__ __launch_bounds__(256) void k_xs_pack_w1_dgrad(const float* __restric
 
 // MTW = sixteen-pixel tiles per wave row (4 wave rows: tile heights up to 64 MTW pixels), D = k-steps the global loads run ahead of their LDS
 // stores.  (5, 1): the many-pixel blocks.  (2, 1): few pixels (dense_e4's 4 560: 128-pixel tiles; 164 instead of 230 registers).  D = 3 on the
-// small tile was built to cover the ~2 us load latency of a 0.24 us k-step (36 MFMAs) and measured SLOWER (dense_e4, C = 2064: 91 vs 63 us alone,
-// 51.6 vs 51.2 ms per step): hipcc's waitcnt insertion drains the queue to 3 outstanding loads at the head of every third unrolled step
-// (s_waitcnt vmcnt(3) in front of the first set's loads), so the lead is lost again - a hand-placed vmcnt is what it would take.
+// small tile was built to cover the load latency of a 0.24 us k-step (36 MFMAs) and measured: with an exit per unrolled step hipcc's waitcnt
+// insertion drained the queue at the head of the body (s_waitcnt vmcnt(3)); with the steps padded to a multiple of D (one exit) the waits are
+// the intended vmcnt(13-14) - and the kernel is NO faster (dense_e4, C = 432 / 1248 / 2064: 44 / 53 / 90 us against 43 / 53 / 63 at D = 1).
+// Latency is not what it waits for: at C = 1248 the 252 workgroups move 227 MB of weight and gradient slabs through the L2 in 40 us (5.7 TB/s)
+// - every one of the 36 pixel tiles re-reads the layer's packed weights.
 template <bool MASK, int NP, int MTW, int D>
 __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
   constexpr int X1_MTW = MTW, X1_G_IMG = 4 * MTW * 16 * 64, X1_STAGE = 2 * X1_G_IMG + 2 * X1_W_IMG;
@@ -654,12 +656,14 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
 #pragma unroll
   for (int d = 1; d < D; ++d) load_slab(d, d);                 // k-steps 1 .. D - 1 in flight
   __syncthreads();
-  for (int j0 = 0; j0 < p.ksteps; j0 += D) {
+  // (the k-steps are padded to a multiple of D with all-zero steps - both operands read as zeros past the end - so that the unrolled body has ONE
+  // exit: with an exit per unrolled step hipcc's waitcnt insertion drained the load queue at the head of the body)
+  const int ksteps_pad = (p.ksteps + D - 1) / D * D;
+  for (int j0 = 0; j0 < ksteps_pad; j0 += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       const int j = j0 + u;
-      if (j >= p.ksteps) break;
-      const bool more = j + 1 < p.ksteps;
+      const bool more = j + 1 < ksteps_pad;
       const unsigned char* const st = x1_smem + (j & 1) * X1_STAGE;
       load_slab(u, j + D);                                      // in flight under D k-steps of MFMAs (set u held k-step j: stored one step ago)
       bf16x8 gh[X1_MTW], gl[X1_MTW];
