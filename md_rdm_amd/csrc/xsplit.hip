@@ -1301,6 +1301,8 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   k.ctiles = ctiles;
   // tile height: one workgroup per CU; the cheapest (rounds of 256 workgroups x tile height) wins.  Few pixels: the small-tile instantiation
   // (<= 128 pixels, three k-steps of loads in flight)
+  // (tile heights swept per shape, alone: dense_e4 is best at the 128 pixels this picks - 51 / 65 us at C = 1248 / 2064 against 67-83 / 77-126 for
+  // 160-320 pixels; at dense_e3 the small instantiation wins below C ~ 500 (90 vs 107-115 us) and loses above (155 vs 139): left on the large one)
   const bool small = M <= 8192;
   const int mtw = small ? X1_MTW_SMALL : X1_MTW_BIG;
   int best_pt = 1; long best_cost = -1;
