@@ -15,6 +15,9 @@ struct BnBatch { BnBatchEntry e[BN_BATCH]; };
 int launch_bn_finalize_batch(const BnBatch& bb, int count, int max_c, hipStream_t s);
 int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const float* gamma, const float* mean, const float* rstd, float* A,
                          float* Bc, float* Cc, float* dgamma, float* dbeta, int C, int training, hipStream_t s);
+int launch_bn_bwd_defer(float* G, int ldg, const float* x, int ldx, const double* s0, const double* s1, double count, const float* gamma, const float* mean,
+                        const float* rstd, float* dgamma, float* dbeta, const float* b_in, const float* c_in, float* b_out, float* c_out, int M, int C,
+                        int slice_c0, int slice_n, int training, hipStream_t s);
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
                         int training, hipStream_t s, bool bf16_rows = false);

@@ -180,6 +180,78 @@ int launch_bn_bwd_coeffs(const double* s0, const double* s1, double count, const
   return 0;
 }
 
+// Deferred norm1 backward (RDM_NET_OPT_DEFER_NORM1).  The BatchNorm backward of a dense layer's norm1 adds  a*dz + b*x + c  into the block
+// gradient G over ALL the layer's input channels - an O(layers^2) elementwise pass (k_bn_bwd_apply<true>).  a = gamma * rstd is known before the
+// layer's dgrad runs, so the 1x1 dgrad's epilogue adds a*dz itself; b and c (they need the dgrad's channel sums) only multiply x and 1, and x - the
+// block buffer's channel - is the same for every layer that reads it: the (b, c) of all layers are SUMMED per channel (ping-pong running sums:
+// layer i reads `in`, writes `out` for its channels < C) and applied when a channel's gradient is needed next - the 48 channels
+// [slice_c0, slice_c0 + slice_n) that the next layer down produced (or the block's input channels after its first layer).  This kernel: the
+// layer's coefficients, dgamma / dbeta, the running sums, and the slice's  G += B x + C.
+__global__ __launch_bounds__(256) void k_bn_bwd_defer(float* __restrict__ G, int ldg, const float* __restrict__ x, int ldx, const double* __restrict__ s0,
+                                                     const double* __restrict__ s1, double inv_count, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, const float* __restrict__ b_in, const float* __restrict__ c_in,
+                                                     float* __restrict__ b_out, float* __restrict__ c_out, int M, int C, int slice_c0, int slice_n,
+                                                     int training) {
+  extern __shared__ float defer_lds[];                                // [slice_n] B | [slice_n] C
+  float* const sB = defer_lds;
+  float* const sC = defer_lds + slice_n;
+  const int tid = threadIdx.x;
+  auto coeffs = [&](int c, float& fb, float& fc, float& dg, float& db) {      // the arithmetic of k_bn_bwd_apply
+    const double mu = mean[c], rs = rstd[c], g = gamma[c];
+    const double sdz = s0[c], sdzx = s1[c];
+    const double sdzxhat = rs * (sdzx - mu * sdz);
+    dg = (float)sdzxhat; db = (float)sdz;
+    fb = 0.f; fc = 0.f;
+    if (training) {
+      const double aa = g * rs, m1 = sdz * inv_count, m2 = sdzxhat * inv_count;
+      const double bb = -aa * rs * m2;
+      fb = (float)bb; fc = (float)(-aa * m1 - bb * mu);
+    }
+  };
+  for (int i = tid; i < slice_n; i += 256) {
+    const int c = slice_c0 + i;
+    float fb, fc, dg, db;
+    coeffs(c, fb, fc, dg, db);
+    sB[i] = b_in[c] + fb; sC[i] = c_in[c] + fc;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = tid; c < C; c += 256) {
+      float fb, fc, dg, db;
+      coeffs(c, fb, fc, dg, db);
+      b_out[c] = b_in[c] + fb; c_out[c] = c_in[c] + fc;
+      if (dgamma) dgamma[c] = dg;
+      if (dbeta) dbeta[c] = db;
+    }
+  }
+  __syncthreads();
+  const int Q = slice_n >> 2;
+  const long total = (long)M * Q;
+  for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / Q;
+    const int c = (int)(i - m * Q) * 4;
+    float* gp = G + m * ldg + slice_c0 + c;
+    float4 gv = ld4(gp);
+    const float4 xv = ld4(x + m * ldx + slice_c0 + c);
+    gv.x += fmaf(sB[c], xv.x, sC[c]); gv.y += fmaf(sB[c + 1], xv.y, sC[c + 1]);
+    gv.z += fmaf(sB[c + 2], xv.z, sC[c + 2]); gv.w += fmaf(sB[c + 3], xv.w, sC[c + 3]);
+    st4(gp, gv);
+  }
+}
+
+int launch_bn_bwd_defer(float* G, int ldg, const float* x, int ldx, const double* s0, const double* s1, double count, const float* gamma, const float* mean,
+                        const float* rstd, float* dgamma, float* dbeta, const float* b_in, const float* c_in, float* b_out, float* c_out, int M, int C,
+                        int slice_c0, int slice_n, int training, hipStream_t s) {
+  RDM_CHECK_ARG(slice_n > 0 && slice_n % 4 == 0 && slice_c0 % 4 == 0 && slice_c0 + slice_n <= C && ldg % 4 == 0 && ldx % 4 == 0 && slice_n <= 4096,
+                "bn_bwd_defer: slice [%d, +%d) of %d channels", slice_c0, slice_n, C);
+  const long total = (long)M * (slice_n / 4);
+  const unsigned blocks = (unsigned)std::min<long>(std::max<long>(cdiv(total, 256 * 4), 1), 2048);
+  hipLaunchKernelGGL(k_bn_bwd_defer, dim3(blocks), dim3(256), (size_t)slice_n * 8, s, G, ldg, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, b_in,
+                     c_in, b_out, c_out, M, C, slice_c0, slice_n, training);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
 // Zero fill as an ordinary kernel.  hipMemsetAsync / hipMemset2DAsync go through the runtime's fill path, which
 // showed up as ~0.8 ms of GPU idle time per step in front of 360 fills (kernel trace); a plain launch queues back-to-back.
 // rows x row_floats floats with a row pitch of `ld` floats (ld == row_floats: contiguous).  All multiples of 4, 16-B aligned.

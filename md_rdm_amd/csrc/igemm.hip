@@ -938,7 +938,7 @@ int launch_conv_fwd(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStrea
 
 static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue epi, hipStream_t s) {
   FwdArgs a = a_in;
-  RDM_CHECK_ARG(!a.out_bf16 && !a.a_bf16, "conv: bf16 rows are read / written by the one-product kernels of xsplit.hip only");
+  RDM_CHECK_ARG(!a.out_bf16 && !a.a_bf16 && !a.acc_scaled, "conv: bf16 rows / the scaled accumulating epilogue belong to the kernels of xsplit.hip only");
   RDM_CHECK_ARG(a.C % 16 == 0 && a.C > 0, "conv: contracted channels (%d) must be a positive multiple of 16", a.C);
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldw % 4 == 0 && a.wtap % 4 == 0, "conv: strides must be multiples of 4 floats");
   RDM_CHECK_ARG(!b_kstrided || a.N % 4 == 0, "dgrad: N (%d) must be a multiple of 4", a.N);

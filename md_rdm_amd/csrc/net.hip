@@ -199,6 +199,7 @@ struct NetImpl {
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
   size_t xsW = 0, xsWBytes = 0, xfW = 0, xfWBytes = 0;
+  size_t deferBC = 0; int deferLd = 0;      // deferred norm1 backward: [parity 2][B | C][deferLd] running per-channel sums of the block being walked
   std::vector<size_t> winoU[4];
   size_t total;
   int training_saved = 1;
@@ -213,6 +214,7 @@ struct NetImpl {
   // the decoder (1 280 pixels) loses overall (53.3 vs 52.6 ms per step)
   int xs_min_pixels = 4096;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
+  int opt_defer_norm1 = 1;     // RDM_NET_OPT_DEFER_NORM1: see k_bn_bwd_defer (elementwise.hip); blocks on the xs 1x1 dgrad only
   int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
   int xs_np() const { return (opt_gemm_bf16 & 2) ? 1 : 3; }      // value bits: 1 = the forward GEMMs, 2 = the gradient GEMMs (3 = both)
   int opt_split_fwd = 0;       // RDM_NET_OPT_SPLIT_FWD: conv1 of the many-pixel blocks on the three-way-split bf16x6 forward kernel
@@ -349,6 +351,8 @@ struct NetImpl {
     for (int b = 0; b < 4; ++b)
       if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
+    for (int b = 0; b < 4; ++b) deferLd = std::max(deferLd, (bg[b].ctot + 63) / 64 * 64);
+    deferBC = a.take<float>((size_t)4 * deferLd);
     for (int b = 0; b < 4; ++b)
       if (bg[b].M >= 1024) xfWBytes = std::max(xfWBytes, xs_fwd1x1_workspace_bytes(bg[b].ctot, bg[b].cb));
     xfW = a.take<unsigned char>(xfWBytes);
@@ -699,11 +703,26 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
     e.a_bf16 = dz_bf16;
-    if (n.xs_block(b) && xs_dgrad1x1_supported(e)) {
+    const bool xs_d1 = n.xs_block(b) && xs_dgrad1x1_supported(e);
+    const bool defer = xs_d1 && n.opt_defer_norm1;
+    if (defer) { e.out = G; e.ldc = g.ctot; e.acc_scaled = 1; }          // the epilogue adds (gamma * rstd) * dz into the block gradient itself
+    if (xs_d1) {
       if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
     } else if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
-    if ((rc = launch_bn_bwd_apply(G, g.ctot, dZ1, cin, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
-                                  Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
+    if (defer) {
+      // ... the b * x + c terms of all layers are summed per channel and applied to the channels whose gradient is read next: the 48 the layer
+      // below produced, or the block's input channels after its first layer
+      float* bc = at<float>(ws, n.deferBC);
+      float* b_in = bc + (size_t)((i + 1) & 1) * 2 * n.deferLd;
+      float* b_out = bc + (size_t)(i & 1) * 2 * n.deferLd;
+      if (i == kBlocks[b].layers - 1 && (rc = zero_f32(b_in, (size_t)2 * n.deferLd, s))) return rc;
+      const int sc0 = i > 0 ? cin - GROWTH : 0, sn = i > 0 ? GROWTH : cin;
+      if ((rc = launch_bn_bwd_defer(G, g.ctot, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
+                                    Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, b_in, b_in + n.deferLd, b_out,
+                                    b_out + n.deferLd, g.M, cin, sc0, sn, training, s)))
+        return rc;
+    } else if ((rc = launch_bn_bwd_apply(G, g.ctot, dZ1, cin, blk, g.ctot, s0, s1, (double)g.M, F(T, L.bn1.w), bn1 + 2 * cin, bn1 + 3 * cin,
+                                         Gr[L.bn1.w] ? F(Gr, L.bn1.w) : nullptr, Gr[L.bn1.b] ? F(Gr, L.bn1.b) : nullptr, g.M, cin, true, training, s)))
       return rc;
   }
   // join: everything the side stream produced (weight gradients) is ordered before what the caller enqueues next.  A caller that
@@ -799,6 +818,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
   else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
+  else if (option == RDM_NET_OPT_DEFER_NORM1) n->opt_defer_norm1 = getenv("RDM_DEFER_NORM1") ? atoi(getenv("RDM_DEFER_NORM1")) != 0 : value != 0;      // (the environment wins: A/B runs of bench.py)
   else if (option == RDM_NET_OPT_GEMM_BF16) n->opt_gemm_bf16 = value == 1 ? 3 : value == 2 ? 1 : value == 3 ? 2 : 0;      // 1 = both, 2 = forward GEMMs only, 3 = gradient GEMMs only
   else if (option == RDM_NET_OPT_SPLIT_FWD) { n->opt_split_fwd = value != 0; if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = atoi(getenv("RDM_XF_MIN_PIXELS")); }
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }

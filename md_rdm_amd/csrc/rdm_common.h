@@ -103,6 +103,8 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   // mixed-precision arithmetic mode, xsplit.hip kernels with one bf16 MFMA per product only: `out` (3x3 dgrad) / `A` (1x1 dgrad) are rows of bf16
   // (ldc / lda in elements of that type)
   int out_bf16, a_bf16;
+  // xs 1x1 dgrad with the gate epilogue only: `out` is the block gradient and receives  out += x_scale * (gated dz)  (deferred norm1 backward)
+  int acc_scaled;
 };
 constexpr int RAWBN_MAX_C = 768;
 

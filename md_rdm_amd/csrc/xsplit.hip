@@ -536,6 +536,7 @@ constexpr int x1_lds(int mtw) { return 2 * (2 * (4 * mtw * 16 * 64) + 2 * X1_W_I
 struct XsDgrad1Args {
   const float* G; int ldg; int K;          // dY [M][ldg], K = Cb contracted channels
   int g_bf16;                              // NP == 1 only: dY is rows of bf16 (ldg in elements): staged verbatim, no conversion
+  int acc;                                 // MASK only: out += x_scale * (gated dz) instead of out = gated dz (deferred norm1 backward: out = the block gradient)
   const unsigned char* Wp;                 // [plane][ksteps][C][64 B]
   float* out; int ldc;
   const float* X; int ldx; const float* x_scale; const float* x_shift;
@@ -719,7 +720,17 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
         for (int e = 0; e < 4; ++e) v[e] = fmaf(xv[i][e], xs[e], xt[e]) > 0.f ? v[e] : 0.f;
         if (ok) { s0 += v; s1 += v * xv[i]; }
       }
-      if (ok) *reinterpret_cast<f32x4*>(p.out + (long)m * p.ldc + c4) = v;       // (plain global stores: see the note in xs_dgrad3x3_kernel)
+      if (ok) {                                                                    // (plain global stores: see the note in xs_dgrad3x3_kernel)
+        float* const o = p.out + (long)m * p.ldc + c4;
+        if (MASK && p.acc) {
+          f32x4 gv = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] = fmaf(xs[e], v[e], gv[e]);
+          *reinterpret_cast<f32x4*>(o) = gv;
+        } else {
+          *reinterpret_cast<f32x4*>(o) = v;
+        }
+      }
     }
     if (MASK) {
 #pragma unroll
@@ -1291,6 +1302,8 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
     RDM_LAUNCH_OK();
   }
   XsDgrad1Args k{};
+  RDM_CHECK_ARG(!a.acc_scaled || epi == EPI_MASK_STATS, "1x1 dgrad: the accumulating epilogue comes with the gate");
+  k.acc = a.acc_scaled;
   k.G = a.A; k.ldg = a.lda; k.K = K; k.g_bf16 = a.a_bf16; k.Wp = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
   k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
   k.M = (int)M; k.C = C; k.ksteps = ksteps;

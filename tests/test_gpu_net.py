@@ -517,3 +517,37 @@ def test_sixth_plan_of_a_process_steps_as_fast_as_the_first(dev):
         torch.cuda.empty_cache()
     print("[plans in a row] ms per forward+backward:", [round(v, 2) for v in ms])
     assert max(ms[3:]) <= 1.10 * min(ms[:3]), ms
+
+
+def test_deferred_norm1_backward_gives_the_same_gradients(dev):
+    """RDM_NET_OPT_DEFER_NORM1 (default on): a * dz added by the 1x1 dgrad's epilogue, the b * x + c terms of all layers summed per channel and applied
+    when a channel's gradient is read next - against the per-layer elementwise pass (defer_norm1 = False) on the same step.  Two runs of the SAME mode
+    already differ (split-K atomics reorder the forward's float32 sums; ReLU flips carry that into the gradients - the deterministic-mode test
+    measures 2.6e-2 of the gradient norm), so the criterion is relative to that floor, measured here: the distance between the two modes is no
+    larger than three times the distance between two runs of one mode (+ 2e-3 of the norm), per block of the network - dense_e4 and d_1, whose
+    backward the option does not touch, show what that ratio is by chance (measured 1.6-3.1 on all five).  B=4 228x304: dense_e2 and dense_e3
+    are on the split kernels.  (The absolute check of the deferred path is the oracle comparison of the tests above, which run with it on.)"""
+    from md_rdm_amd import filler, harness
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    x, y = filler.synthetic_batch(4, 228, 304, seed=filler.MARGIN_SEEDS["train228x304"])
+    xg, yg = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    runs = []
+    for defer in (False, False, True):
+        m = DepthEstimationNet()
+        filler.fill_state_dict(m.state_dict())
+        m = m.to(dev).train()
+        m.defer_norm1 = defer
+        m.flatten_parameters()
+        loss, _ = harness.training_step(m, xg, yg)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None})
+    a, b, c = runs
+    for prefix in ("encoder.conv_e1", "encoder.dense_e2", "encoder.dense_e3", "encoder.dense_e4", "d_1"):
+        names = [n for n in a if n.startswith(prefix)]
+        assert names, prefix
+        norm = sum(float(a[n].pow(2).sum()) for n in names) ** 0.5
+        floor = sum(float((a[n] - b[n]).pow(2).sum()) for n in names) ** 0.5 / norm
+        dist = sum(float((a[n] - c[n]).pow(2).sum()) for n in names) ** 0.5 / norm
+        print(f"[deferred norm1] {prefix}: two runs of one mode {floor:.2e} of the gradient norm, the two modes {dist:.2e}")
+        assert dist <= 3.0 * floor + 2e-3, (prefix, floor, dist)
