@@ -303,6 +303,9 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                the block gradient itself, and the remaining terms of the norm1 BatchNorm backward (b * x + c per channel, which need the
  *                                kernel's channel sums) are summed over the layers and applied once per channel when its gradient is read next, instead of
  *                                one elementwise pass over all input channels per layer.  Same gradients to float32 rounding.
+ *   RDM_NET_OPT_PREPACK          (default 1) the weight images of the split kernels (three-way split for the 1x1 forward, fragment order / transposed split
+ *                                for the two input-gradient kernels) are formed for ALL layers once per training step on the library's side stream at the
+ *                                start of rdm_net_forward, instead of by one small launch in front of every kernel on the dependent chain.
  *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic (the reference's default --precision 16, train.py:11,57-58): every launch that
  *                                RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels rounds its operands to bf16 instead (ONE bf16
  *                                MFMA per product, float32 accumulation).  value 1 = forward and gradient GEMMs, 2 = forward only, 3 = gradient GEMMs
@@ -310,7 +313,7 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                GEMMs in this mode the per-layer dZ -> dY scratch tensor is kept as bf16.  Not the parity configuration: tolerance
  *                                stated in tests/test_gpu_mixed.py. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9, RDM_NET_OPT_PREPACK = 10 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -183,6 +183,8 @@ struct NetImpl {
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[0], hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_dz[1], hipEventDisableTiming));
     RDM_HIP_OK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_pkf, hipEventDisableTiming));
+    RDM_HIP_OK(hipEventCreateWithFlags(&ev_pkb, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       RDM_HIP_OK(hipEventCreateWithFlags(&ev_fs[i], hipEventDisableTiming));
       RDM_HIP_OK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming));
@@ -190,7 +192,7 @@ struct NetImpl {
     return 0;
   }
   ~NetImpl() {
-    if (side) { hipStreamSynchronize(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
+    if (side) { hipStreamSynchronize(side); hipEventDestroy(ev_go); hipEventDestroy(ev_dy); hipEventDestroy(ev_dz[0]); hipEventDestroy(ev_dz[1]); hipEventDestroy(ev_side); hipEventDestroy(ev_pkf); hipEventDestroy(ev_pkb); hipEventDestroy(ev_fs[0]); hipEventDestroy(ev_fs[1]); hipEventDestroy(ev_fa[0]); hipEventDestroy(ev_fa[1]); }
   }
   // Winograd F(2x2, 3x3) for the 3x3 convs of the blocks with many pixels (wino.hip): transformed weights per layer (formed on the side
   // stream at the start of forward) and one scratch for the per-split partial outputs
@@ -199,6 +201,12 @@ struct NetImpl {
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
   size_t xsW = 0, xsWBytes = 0, xfW = 0, xfWBytes = 0;
+  // per-layer packed weights of the split kernels (formed once per training step on the side stream at the start of the forward, off the
+  // dependent chains): 3x3 dgrad / 1x1 dgrad / 1x1 forward images; empty where the block is below the kernels' default pixel thresholds
+  std::vector<size_t> xsP3[4], xsP1[4], xfP[4];
+  bool pk_fwd_valid = false, pk_bwd_valid = false;
+  hipEvent_t ev_pkf = nullptr, ev_pkb = nullptr;
+  int opt_prepack = 1;
   size_t deferBC = 0; int deferLd = 0;      // deferred norm1 backward: [parity 2][B | C][deferLd] running per-channel sums of the block being walked
   std::vector<size_t> winoU[4];
   size_t total;
@@ -351,6 +359,19 @@ struct NetImpl {
     for (int b = 0; b < 4; ++b)
       if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
+    for (int b = 0; b < 4; ++b) {
+      if (bg[b].M >= 4096) {
+        xsP3[b].resize(kBlocks[b].layers); xsP1[b].resize(kBlocks[b].layers);
+        for (int i = 0; i < kBlocks[b].layers; ++i) {
+          xsP3[b][i] = a.take<unsigned char>(xs_dgrad3x3_workspace_bytes(bg[b].cb));
+          xsP1[b][i] = a.take<unsigned char>(xs_dgrad1x1_workspace_bytes(bg[b].cb, kBlocks[b].cin + i * GROWTH));
+        }
+      }
+      if (bg[b].M >= 8192) {
+        xfP[b].resize(kBlocks[b].layers);
+        for (int i = 0; i < kBlocks[b].layers; ++i) xfP[b][i] = a.take<unsigned char>(xs_fwd1x1_workspace_bytes(kBlocks[b].cin + i * GROWTH, bg[b].cb));
+      }
+    }
     for (int b = 0; b < 4; ++b) deferLd = std::max(deferLd, (bg[b].ctot + 63) / 64 * 64);
     deferBC = a.take<float>((size_t)4 * deferLd);
     for (int b = 0; b < 4; ++b)
@@ -439,8 +460,11 @@ int conv1_range(NetImpl& n, int b, int i, int c_lo, int c_hi, bool accumulate, b
     a.a_scale = nullptr; a.a_shift = nullptr;
     a.a_sum = bst + c_lo; a.a_sq = bst + g.ctot + c_lo; a.a_gamma = F(T, L.bn1.w) + c_lo; a.a_beta = F(T, L.bn1.b) + c_lo; a.a_count = (double)g.M;
   }
-  if (n.xf_block(b) && !accumulate && !add_out && !raw_bn && xs_fwd1x1_supported(a))
-    return launch_xs_fwd1x1(a, fuse ? EPI_STORE_STATS : EPI_STORE, at<unsigned char>(ws, n.xfW), n.xfWBytes, s, (n.opt_gemm_bf16 & 1) ? 1 : 6);
+  if (n.xf_block(b) && !accumulate && !add_out && !raw_bn && xs_fwd1x1_supported(a)) {
+    const bool pk = n.pk_fwd_valid && !n.xfP[b].empty() && c_lo == 0 && c_hi == cin;
+    return launch_xs_fwd1x1(a, fuse ? EPI_STORE_STATS : EPI_STORE, at<unsigned char>(ws, pk ? n.xfP[b][i] : n.xfW), pk ? xs_fwd1x1_workspace_bytes(cin, g.cb) : n.xfWBytes, s,
+                            (n.opt_gemm_bf16 & 1) ? 1 : 6, pk);
+  }
   const int rc = launch_conv_fwd(a, false, fuse ? EPI_STORE_STATS : EPI_STORE, s);
   return rc < 0 ? rc : 0;
 }
@@ -458,6 +482,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
   const bool pipelined = !fuse_stats(g.M, g.cb) && layers > 1 && g_variant != 8 && !n.opt_det;   // part A / part B add atomically: not in deterministic mode
   hipStream_t side = n.side;
   int rc;
+  if (b == 0 && n.pk_fwd_valid) RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_pkf, 0));                 // the packed conv1 weights of the split forward kernel
   // Few-pixel blocks in training (round 3): the two BatchNorm finalisations of a layer leave the dependent chain - the consuming conv
   // forms (scale, shift) from the channel sums itself (RAW prologue), the running statistics and the coefficients backward needs are written
   // by BATCHED finalisation launches (24 BatchNorms each) - and the 48-channel output slices of ALL layers are zeroed by ONE launch at the start
@@ -668,7 +693,8 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     }
     d.out_bf16 = dz_bf16;
     if (n.xs_block(b) && xs_dgrad3x3_supported(d)) {
-      if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
+      const bool pk = n.pk_bwd_valid && !n.xsP3[b].empty();
+      if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, pk ? n.xsP3[b][i] : n.xsW), pk ? xs_dgrad3x3_workspace_bytes(cb) : n.xsWBytes, s, n.xs_np(), pk))) return rc;
     } else if ((rc = launch_conv_fwd(d, true, EPI_MASK_STATS, s)) < 0) return rc;      // split-K layers gate + reduce atomically
     // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
     // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
@@ -707,7 +733,8 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     const bool defer = xs_d1 && n.opt_defer_norm1;
     if (defer) { e.out = G; e.ldc = g.ctot; e.acc_scaled = 1; }          // the epilogue adds (gamma * rstd) * dz into the block gradient itself
     if (xs_d1) {
-      if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, n.xsW), n.xsWBytes, s, n.xs_np()))) return rc;
+      const bool pk = n.pk_bwd_valid && !n.xsP1[b].empty();
+      if ((rc = launch_xs_dgrad1x1(e, EPI_MASK_STATS, at<unsigned char>(ws, pk ? n.xsP1[b][i] : n.xsW), pk ? xs_dgrad1x1_workspace_bytes(cb, cin) : n.xsWBytes, s, n.xs_np(), pk))) return rc;
     } else if ((rc = launch_conv_fwd(e, true, EPI_MASK_STATS, s)) < 0) return rc;
     if (defer) {
       // ... the b * x + c terms of all layers are summed per channel and applied to the channels whose gradient is read next: the 48 the layer
@@ -818,6 +845,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
   else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
+  else if (option == RDM_NET_OPT_PREPACK) n->opt_prepack = getenv("RDM_PREPACK") ? atoi(getenv("RDM_PREPACK")) != 0 : value != 0;
   else if (option == RDM_NET_OPT_DEFER_NORM1) n->opt_defer_norm1 = getenv("RDM_DEFER_NORM1") ? atoi(getenv("RDM_DEFER_NORM1")) != 0 : value != 0;      // (the environment wins: A/B runs of bench.py)
   else if (option == RDM_NET_OPT_GEMM_BF16) n->opt_gemm_bf16 = value == 1 ? 3 : value == 2 ? 1 : value == 3 ? 2 : 0;      // 1 = both, 2 = forward GEMMs only, 3 = gradient GEMMs only
   else if (option == RDM_NET_OPT_SPLIT_FWD) { n->opt_split_fwd = value != 0; if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = atoi(getenv("RDM_XF_MIN_PIXELS")); }
@@ -900,6 +928,18 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
   if ((rc = n.ensure_side())) return rc;
   RDM_HIP_OK(hipEventRecord(n.ev_go, s));
   RDM_HIP_OK(hipStreamWaitEvent(n.side, n.ev_go, 0));
+  // split kernels: the three-way-split images of the conv1 weights the forward reads first (dense_e2's first layer starts ~0.3 ms from here)
+  n.pk_fwd_valid = n.pk_bwd_valid = false;
+  if (n.opt_prepack && n.opt_split_fwd && !n.opt_det) {
+    for (int b = 0; b < 4; ++b)
+      if (n.xf_block(b) && !n.xfP[b].empty())
+        for (int i = 0; i < kBlocks[b].layers; ++i) {
+          const int cin = kBlocks[b].cin + i * GROWTH;
+          if ((rc = launch_xs_pack_w1_fwd(F(T, reg().layers[b][i].conv1), cin, n.bg[b].cb, cin, at<unsigned char>(ws, n.xfP[b][i]), n.side))) return rc;
+        }
+    RDM_HIP_OK(hipEventRecord(n.ev_pkf, n.side));
+    n.pk_fwd_valid = true;
+  }
   if (!n.opt_packed3x3)
     for (int b = 0; b < 4; ++b)
       for (int i = 0; i < kBlocks[b].layers; ++i)
@@ -911,6 +951,20 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
         if ((rc = launch_wino_weight(w2p, (long)GROWTH * n.bg[b].cb, n.bg[b].cb, GROWTH, n.bg[b].cb, at<float>(ws, n.winoU[b][i]), n.side))) return rc;
       }
   RDM_HIP_OK(hipEventRecord(n.ev_side, n.side));
+  // ... and, behind everything the forward waits for, the split / fragment-order images the BACKWARD's input-gradient kernels read (the weights
+  // do not change between this forward and its backward): 108 launches that used to sit on the backward's dependent chain
+  if (training && n.opt_prepack && n.opt_split_bwd && !n.opt_det) {
+    for (int b = 3; b >= 0; --b)
+      if (n.xs_block(b) && !n.xsP3[b].empty())
+        for (int i = kBlocks[b].layers - 1; i >= 0; --i) {
+          const int cin = kBlocks[b].cin + i * GROWTH, cb = n.bg[b].cb;
+          const float* w2p = n.opt_packed3x3 ? F(T, reg().layers[b][i].conv2) : at<float>(ws, n.lws[b][i].w2p);
+          if ((rc = launch_xs_pack_w3_dgrad(w2p, (long)GROWTH * cb, cb, cb, at<unsigned char>(ws, n.xsP3[b][i]), n.side))) return rc;
+          if ((rc = launch_xs_pack_w1_dgrad(F(T, reg().layers[b][i].conv1), cin, cb, cin, at<unsigned char>(ws, n.xsP1[b][i]), n.side))) return rc;
+        }
+    RDM_HIP_OK(hipEventRecord(n.ev_pkb, n.side));
+    n.pk_bwd_valid = true;
+  }
   // stem: 7x7/s2 conv as im2col + GEMM (K = 147 padded to 160), bias, then 3x3/s2 max-pool
   if ((rc = launch_im2col_stem(x, at<float>(ws, n.patches), n.B, n.H0, n.W0, s))) return rc;
   RDM_HIP_OK(hipMemsetAsync(at<float>(ws, n.stem_wp), 0, 96 * 160 * sizeof(float), s));
@@ -1128,6 +1182,7 @@ static int backward_stem(NetImpl& n, void* ws, void* const* T, void* const* Gr, 
 static int backward_stage(NetImpl& n, int stage, const float* dlogits, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
   const Registry::Stage& st = reg().stages[stage];
   int rc;
+  if (stage == 0 && n.pk_bwd_valid) RDM_HIP_OK(hipStreamWaitEvent(s, n.ev_pkb, 0));      // the packed weights of the input-gradient kernels (long done)
   if (st.first_of_seg) {
     if (st.seg == 0) { if ((rc = backward_head(n, dlogits, ws, T, Gr, s))) return rc; }
     else if ((rc = backward_transition(n, st.block, ws, T, Gr, s))) return rc;          // seg 1 -> trans_e4 (t = 2) feeding dense_e4 (b = 2), ...

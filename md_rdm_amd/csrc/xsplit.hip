@@ -1234,7 +1234,14 @@ bool xs_dgrad3x3_supported(const FwdArgs& a) {
          a.N % 16 == 0 && a.N >= 16 && xs_dgrad3_lds_bytes(g.W) <= 156 * 1024 && (g.W + 2) * XD_SLOT < 32768 && a.bias == nullptr && !a.accumulate && !a.add_out;
 }
 
-int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
+int launch_xs_pack_w3_dgrad(const float* w, long wtap, int ldw, int Cb, void* ws, hipStream_t s) {
+  const long threads = (long)(Cb / 16) * XD_KSTEPS * 64;
+  hipLaunchKernelGGL(k_xs_pack_w3_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, wtap, ldw, Cb, static_cast<unsigned char*>(ws));
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np, bool prepacked) {
   RDM_CHECK_ARG(xs_dgrad3x3_supported(a), "split-precision 3x3 dgrad: needs a 3x3 / stride 1 / pad 1 convolution with 48 gradient channels, N (%d) a multiple of 16, W (%d) <= 339", a.N, a.g.W);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 3x3 dgrad: plain or gate + statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 3x3 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1244,11 +1251,7 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   const long gb = ((M - 1) * a.lda + 48) * 4, ob = ((M - 1) * a.ldc + a.N) * 4, xb = a.X ? ((M - 1) * a.ldx + a.N) * 4 : 16;
   if (gb >= 0xFFFFFFFFL || ob >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 3x3 dgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
   const int Cb = a.N;
-  {
-    const long threads = (long)(Cb / 16) * XD_KSTEPS * 64;
-    hipLaunchKernelGGL(k_xs_pack_w3_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.wtap, a.ldw, Cb, static_cast<unsigned char*>(ws));
-    RDM_LAUNCH_OK();
-  }
+  if (!prepacked) { if (int prc = launch_xs_pack_w3_dgrad(a.Wt, a.wtap, a.ldw, Cb, ws, s)) return prc; }
   XsDgrad3Args k{};
   k.G = a.A; k.ldg = a.lda; k.Wf = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
   k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
@@ -1285,7 +1288,15 @@ bool xs_dgrad1x1_supported(const FwdArgs& a) {
   return one && a.N % 16 == 0 && a.N >= 16 && a.N <= 12 * X1_BNMAX && a.C % 4 == 0 && a.C >= 32 && a.bias == nullptr && !a.accumulate && !a.add_out;
 }
 
-int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
+int launch_xs_pack_w1_dgrad(const float* w, int ldw, int K, int C, void* ws, hipStream_t s) {
+  const int ksteps = (K + 31) / 32;
+  const long threads = (long)ksteps * 4 * C;
+  hipLaunchKernelGGL(k_xs_pack_w1_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, ldw, K, C, ksteps, static_cast<unsigned char*>(ws));
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np, bool prepacked) {
   RDM_CHECK_ARG(xs_dgrad1x1_supported(a), "split-precision 1x1 dgrad: needs a 1x1 / stride 1 convolution, 16 <= N (%d) <= %d a multiple of 16, C (%d) a multiple of 4", a.N, 12 * X1_BNMAX, a.C);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_MASK_STATS, "split-precision 1x1 dgrad: plain or gate + statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 dgrad: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1296,11 +1307,7 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   RDM_CHECK_ARG(!a.a_bf16 || np == 1, "1x1 dgrad: bf16 gradient rows exist in the one-product (mixed-precision) form only");
   const long gb = ((M - 1) * a.lda + K) * (a.a_bf16 ? 2 : 4), xb = a.X ? ((M - 1) * a.ldx + C) * 4 : 16;
   if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 dgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
-  {
-    const long threads = (long)ksteps * 4 * C;
-    hipLaunchKernelGGL(k_xs_pack_w1_dgrad, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.ldw, K, C, ksteps, static_cast<unsigned char*>(ws));
-    RDM_LAUNCH_OK();
-  }
+  if (!prepacked) { if (int prc = launch_xs_pack_w1_dgrad(a.Wt, a.ldw, K, C, ws, s)) return prc; }
   XsDgrad1Args k{};
   RDM_CHECK_ARG(!a.acc_scaled || epi == EPI_MASK_STATS, "1x1 dgrad: the accumulating epilogue comes with the gate");
   k.acc = a.acc_scaled;
@@ -1388,7 +1395,15 @@ bool xs_fwd1x1_supported(const FwdArgs& a) {
   return one && a.N % 16 == 0 && a.N >= 16 && a.C % 4 == 0 && a.C >= 4 && a.bias == nullptr && !a.accumulate && !a.add_out && a.a_sum == nullptr;
 }
 
-int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np) {
+int launch_xs_pack_w1_fwd(const float* w, int ldw, int N, int K, void* ws, hipStream_t s) {
+  const int ksteps = (K + 31) / 32;
+  const long threads = (long)ksteps * N * 4;
+  hipLaunchKernelGGL(k_xs_pack_w1_fwd, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, ldw, N, K, ksteps, static_cast<unsigned char*>(ws));
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np, bool prepacked) {
   RDM_CHECK_ARG(xs_fwd1x1_supported(a), "split-precision 1x1 forward: needs a 1x1 / stride 1 convolution, N (%d) a multiple of 16, C (%d) a multiple of 4, no bias / accumulation", a.N, a.C);
   RDM_CHECK_ARG(epi == EPI_STORE || epi == EPI_STORE_STATS, "split-precision 1x1 forward: plain or statistics epilogue only");
   RDM_CHECK_ARG(a.lda % 4 == 0 && a.ldc % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "split-precision 1x1 forward: strides multiples of 4 floats, tensors 16-byte aligned");
@@ -1399,11 +1414,7 @@ int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, 
   const long M = a.M;
   const long xb = ((M - 1) * a.lda + K) * 4;
   if (xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 forward: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
-  {
-    const long threads = (long)ksteps * N * 4;
-    hipLaunchKernelGGL(k_xs_pack_w1_fwd, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, a.Wt, a.ldw, N, K, ksteps, static_cast<unsigned char*>(ws));
-    RDM_LAUNCH_OK();
-  }
+  if (!prepacked) { if (int prc = launch_xs_pack_w1_fwd(a.Wt, a.ldw, N, K, ws, s)) return prc; }
   XsFwd1Args k{};
   k.X = a.A; k.ldx = a.lda; k.K = K; k.x_scale = a.a_scale; k.x_shift = a.a_shift; k.Wp = static_cast<const unsigned char*>(ws);
   k.out = a.out; k.ldc = a.ldc; k.stat0 = a.stat0; k.stat1 = a.stat1; k.M = (int)M; k.N = N; k.ksteps = ksteps;

@@ -319,6 +319,7 @@ class DepthEstimationNet(BaseModel):
         self.precision = "f32"     # "bf16": eval-mode forward on the bf16 MFMA path (set_precision)
         self.forward_split = True    # conv1 of dense_e2 / dense_e3 on the three-way-split bf16x6 kernel (RDM_NET_OPT_SPLIT_FWD: float32-equivalent accuracy, measured
                                    # 3-9e-7 of the result's maximum against float64 - the f32 MFMA kernel's own level); False: exact-f32 MFMA
+        self.prepack = True          # RDM_NET_OPT_PREPACK: the split kernels' weight images are formed for all layers once per step on the side stream (off the dependent chains)
         self.defer_norm1 = True      # RDM_NET_OPT_DEFER_NORM1: the norm1 BatchNorm backward of the blocks on the split kernels without its O(layers^2) elementwise pass (same gradients to f32 rounding)
         self.gemm_bf16 = 0           # 1 (or True): forward and gradient GEMMs, 2: forward only, 3: gradient GEMMs only - MIXED-PRECISION arithmetic (the reference's default `--precision 16`, train.py:11,57-58): every GEMM the two options
                                    # around this line route to the split kernels rounds its operands to bf16 (one MFMA per product, float32 accumulation);
@@ -412,7 +413,7 @@ class DepthEstimationNet(BaseModel):
             self.flatten_parameters()
 
     def _plan(self, B, H, W):
-        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1))
+        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1), bool(self.prepack))
         if self.backward_precision not in ("f32", "bf16x3"):
             raise ValueError("backward_precision must be 'f32' or 'bf16x3'")
         if key not in self._plans:
@@ -425,6 +426,7 @@ class DepthEstimationNet(BaseModel):
                 _lib.check(L.rdm_net_set_option(h, 4, 1))     # RDM_NET_OPT_DETERMINISTIC
             _lib.check(L.rdm_net_set_option(h, 6, 1 if self.backward_precision == "bf16x3" else 0))     # RDM_NET_OPT_SPLIT_BWD
             _lib.check(L.rdm_net_set_option(h, 7, 1 if self.forward_split else 0))                      # RDM_NET_OPT_SPLIT_FWD
+            _lib.check(L.rdm_net_set_option(h, 10, 1 if self.prepack else 0))                            # RDM_NET_OPT_PREPACK
             _lib.check(L.rdm_net_set_option(h, 9, 1 if self.defer_norm1 else 0))                         # RDM_NET_OPT_DEFER_NORM1
             _lib.check(L.rdm_net_set_option(h, 8, int(self.gemm_bf16)))                          # RDM_NET_OPT_GEMM_BF16
             oh, ow = C.c_int32(), C.c_int32()
