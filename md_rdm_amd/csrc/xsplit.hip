@@ -801,6 +801,10 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
   // offset of (padded position u, this thread's channel quad) or XOOB for a border / out-of-range position
   // (u < 2^21: floor((u + 0.5) / d) through one float multiply is exact - the quotient's error stays far below the 0.5 / d margin)
   const float rPP = 1.0f / (float)PP, rWp = 1.0f / (float)Wp;
+  // (a per-geometry table position -> pixel index in place of this arithmetic - ~20 of the ~45 vector instructions a staged float4 costs - was built and
+  // measured: 50.9-51.2 vs 50.0-50.4 ms per step - the table load in front of every data load costs more than the divisions it saves.  Timing-only
+  // ablations of this kernel at dense_e2, alone: 0.57 ms whole, 0.42 without its MFMAs, 0.38 without its staging, 0.36 staging alone, 0.355 MFMAs alone,
+  // 0.19 with neither (prologue, barriers, gradient fragments, 14 M atomic adds of the 12-way K split): staging and MFMA overlap only by a quarter)
   auto pix_off = [&](int u, int ld, int col, bool colok) -> unsigned {
     const int b = (int)(((float)u + 0.5f) * rPP), rem = u - b * PP, yp = (int)(((float)rem + 0.5f) * rWp), xp = rem - yp * Wp;
     const bool ok = u >= 0 && u < U && colok && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
