@@ -804,7 +804,11 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
   // (a per-geometry table position -> pixel index in place of this arithmetic - ~20 of the ~45 vector instructions a staged float4 costs - was built and
   // measured: 50.9-51.2 vs 50.0-50.4 ms per step - the table load in front of every data load costs more than the divisions it saves.  Timing-only
   // ablations of this kernel at dense_e2, alone: 0.57 ms whole, 0.42 without its MFMAs, 0.38 without its staging, 0.36 staging alone, 0.355 MFMAs alone,
-  // 0.19 with neither (prologue, barriers, gradient fragments, 14 M atomic adds of the 12-way K split): staging and MFMA overlap only by a quarter)
+  // 0.19 with neither (prologue, barriers, gradient fragments, 14 M atomic adds of the 12-way K split): staging and MFMA overlap only by a quarter.
+  // The ISA says why: a slab is ~200 address VALU + 4 loads, THEN 81 MFMAs in 9 bursts with their 4 ds_reads, THEN ~190 convert / split VALU + 8 ds_writes
+  // - the matrix pipe idles through both VALU stretches; only the other workgroup of the CU fills them.  __builtin_amdgcn_sched_group_barrier
+  // pipelines (1 MFMA : 2-5 VALU, with and without DS / VMEM groups) left hipcc's order unchanged; a hand-split of the staging into ~7-instruction
+  // pieces behind every 3 MFMAs is what it would take)
   auto pix_off = [&](int u, int ld, int col, bool colok) -> unsigned {
     const int b = (int)(((float)u + 0.5f) * rPP), rem = u - b * PP, yp = (int)(((float)rem + 0.5f) * rWp), xp = rem - yp * Wp;
     const bool ok = u >= 0 && u < U && colok && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
