@@ -808,7 +808,8 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
   // The ISA says why: a slab is ~200 address VALU + 4 loads, THEN 81 MFMAs in 9 bursts with their 4 ds_reads, THEN ~190 convert / split VALU + 8 ds_writes
   // - the matrix pipe idles through both VALU stretches; only the other workgroup of the CU fills them.  __builtin_amdgcn_sched_group_barrier
   // pipelines (1 MFMA : 2-5 VALU, with and without DS / VMEM groups) left hipcc's order unchanged; a hand-split of the staging into ~7-instruction
-  // pieces behind every 3 MFMAs is what it would take)
+  // pieces behind every 3 MFMAs is what it would take.  Cheaper addresses alone do not help: scalar-stepped frame positions (15 instead of ~45
+  // vector instructions per address, built and measured) left the kernel at 0.52 ms and the step at 50.0-50.3 ms)
   auto pix_off = [&](int u, int ld, int col, bool colok) -> unsigned {
     const int b = (int)(((float)u + 0.5f) * rPP), rem = u - b * PP, yp = (int)(((float)rem + 0.5f) * rWp), xp = rem - yp * Wp;
     const bool ok = u >= 0 && u < U && colok && yp >= 1 && yp <= p.H && xp >= 1 && xp <= p.W;
