@@ -1382,7 +1382,7 @@ int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
   const int max_split = a.split_k > 0 ? a.split_k : 64;
   for (int sp = a.split_k > 0 ? a.split_k : 1; sp <= max_split && sp <= std::max(1, k.nslab / 8); ++sp) {
     const long rounds = ((long)cblocks * sp + 511) / 512;
-    const double cost = rounds * ((k.nslab + sp - 1) / sp + 2.0 * k.ahead + 3.0);
+    const double cost = rounds * ((k.nslab + sp - 1) / sp + 2.0 * k.ahead + 3.0 + 8.0);      // + the epilogue's 27 648 atomic adds per workgroup ~ 8 slabs (swept at dense_e2: 11 splits in one round 493 us, 23 in two rounds 511, 12 - one workgroup too many - 730)
     if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
   }
   k.split = best;
