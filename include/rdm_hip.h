@@ -293,7 +293,7 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                end of each of the 4 SEGMENTS only, not after every stage: for callers that do not consume gradients
  *                                stage by stage (no data-parallel exchange).  The gradients of a segment are complete on the caller's
  *                                stream once its last stage has returned.
- *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 4 096 pixels (dense_e2 / e3 / e4 at the headline
+ *   RDM_NET_OPT_SPLIT_BWD        the weight / input gradient GEMMs of the dense blocks with >= 1 024 pixels (all four blocks at the headline
  *                                geometry; the 3x3 weight gradient from 8 192 pixels) run the split-precision bf16x3 kernels (rdm_conv2d_*_x3, csrc/xsplit.hip) instead of the exact-f32
  *                                MFMA kernels: gradients agree to ~5e-6 of a tensor's maximum, the forward pass is untouched.  Ignored in
  *                                deterministic mode.

@@ -219,8 +219,9 @@ struct NetImpl {
   int opt_split_bwd = 0;       // RDM_NET_OPT_SPLIT_BWD: the backward GEMMs of the many-pixel blocks run the split-precision (bf16x3) kernels of xsplit.hip
   // blocks whose gradient GEMMs run the split-precision kernels: measured per block at B=16 228x304 - dense_e4 (4 560 pixels) gains on the 1x1
   // weight / input gradients and the 3x3 input gradient (173 -> 100, 134 -> 86, 63 -> 45 us per layer) but not on the 3x3 weight gradient (51 -> 56 us);
-  // the decoder (1 280 pixels) loses overall (53.3 vs 52.6 ms per step)
-  int xs_min_pixels = 4096;
+  // the decoder (1 280 pixels) lost overall while every layer paid two weight-pack launches and the norm1 pass on its chain (53.3 vs 52.6 ms per step);
+  // with RDM_NET_OPT_PREPACK and RDM_NET_OPT_DEFER_NORM1 it gains (49.8-50.1 vs 50.4-50.7): the threshold is the kernels' own minimum
+  int xs_min_pixels = 1024;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
   int opt_defer_norm1 = 1;     // RDM_NET_OPT_DEFER_NORM1: see k_bn_bwd_defer (elementwise.hip); blocks on the xs 1x1 dgrad only
   int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
@@ -360,7 +361,7 @@ struct NetImpl {
       if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
     for (int b = 0; b < 4; ++b) {
-      if (bg[b].M >= 4096) {
+      if (bg[b].M >= 1024) {
         xsP3[b].resize(kBlocks[b].layers); xsP1[b].resize(kBlocks[b].layers);
         for (int i = 0; i < kBlocks[b].layers; ++i) {
           xsP3[b][i] = a.take<unsigned char>(xs_dgrad3x3_workspace_bytes(bg[b].cb));
