@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path); gloo only to rehearse N>1 on a one-GPU box")
+    ap.add_argument("--exchange", default=os.environ.get("RDM_DP_EXCHANGE", "all_reduce"), choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: all_reduce per backward stage (default), or reduce-scatter of the gradient bucket -> AdamW on the owned shard -> all-gather of the parameters")
     ap.add_argument("--workload", default="train", choices=["train", "fwd_bf16"],
                     help="train = the headline metric (BASELINE configs[2]); fwd_bf16 = BASELINE configs[1], batch=8 forward-only bf16")
     ap.add_argument("--backward-precision", default="bf16x3", choices=["bf16x3", "f32"],
@@ -251,15 +253,17 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
     x, y = filler.synthetic_batch(B, H, W, seed=1234 + rank)
     xg, yg = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     model.flatten_parameters()
-    sync = parallel.attach(model)
+    sync = parallel.attach(model, exchange=args.exchange)
     opt = harness.FusedAdamW(model, lr=1e-4)
 
     def step():
         opt.zero_grad()
         loss, _ = harness.training_step(model, xg, yg)
         loss.backward()
-        scale = sync.finish()
-        opt.step(grad_scale=scale)
+        if world > 1:
+            opt.step(sync=sync)                               # per bucket: stage k's AdamW as its reduction lands
+        else:
+            opt.step(grad_scale=sync.finish())
         return loss
 
     def note(msg):

@@ -122,3 +122,19 @@ def dorn_safe_mask(logits, thr=DORN_MARGIN):
 def dorn_unsafe_pairs(logits, thr=DORN_MARGIN):
     """Number of (a, b) logit pairs whose ordinal decision could flip under a +-thr perturbation of both logits."""
     return int((~dorn_safe_mask(logits, thr)).sum())
+
+
+def tap_subsample(t):
+    """Element-wise parity lattice for an activation tap: ``t`` is (B, C, H, W) (the reference's NCHW) or (pixels, C) (our pixel-major block
+    buffers); returns the float32 values at every r-th pixel (row-major over B, H, W) and every c-th channel, r = (pixels // 61) | 1,
+    c = (C // 53) | 1: both odd, so the lattice drifts through every lane / tile position class of the kernels' power-of-two and
+    48-multiple tiles; ~60 x 50 values per tap whatever its size (tests/golden/make_golden.py stores them, tests/test_gpu_net.py compares)."""
+    import numpy as np
+    if hasattr(t, "detach"):
+        t = t.detach().cpu()
+        if t.dim() == 4:
+            t = t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+        t = t.numpy()
+    t = np.asarray(t)
+    r, c = (t.shape[0] // 61) | 1, (t.shape[1] // 53) | 1
+    return np.ascontiguousarray(t[::r, ::c], dtype=np.float32)

@@ -77,6 +77,7 @@ class FusedAdamW:
         self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.step_count = 0
         self.m = self.v = None
+        self.sync, self.mode = None, "after the last stage"        # data parallel: set by step(sync=...)
         self.small = torch.optim.AdamW([p for p in model.weight_layer.parameters() if p.requires_grad], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
     def zero_grad(self):
@@ -102,24 +103,53 @@ class FusedAdamW:
             self._ranges, self._ranges_key = [(a, b) for a, b, _ in ranges], key
         return self._ranges
 
-    def step(self, grad_scale=1.0):
+    def _update(self, a, b, grad_scale):
+        """AdamW on the trainable parts of the flat element range [a, b) (one launch per contiguous trainable piece)."""
         from . import _lib
+        flat, gflat, _ = self.model._flat
+        L, st = _lib.lib(), _lib.stream()
+        off = C.c_void_p
+        for ta, tb in self.trainable_ranges():
+            lo, hi = max(a, ta), min(b, tb)
+            if lo < hi:
+                _lib.check(L.rdm_adamw_fused(off(flat.data_ptr() + 4 * lo), off(gflat.data_ptr() + 4 * lo), off(self.m.data_ptr() + 4 * lo),
+                                             off(self.v.data_ptr() + 4 * lo), hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                             self.step_count, float(grad_scale), st))
+
+    def step(self, grad_scale=1.0, sync=None):
+        """``sync`` = the GradSync of a data-parallel run: the update then runs PER BUCKET as each stage's reduction lands
+        (``GradSync.finish(on_reduced=...)``: stage k's wait is a stream dependency and its AdamW launch follows at once, under the
+        reductions still in flight; with the "reduce_scatter" exchange on this rank's shard only, the updated parameters are
+        all-gathered).  Without it: the monolithic update of the whole buffer with the given ``grad_scale`` (what one process runs:
+        2 launches for the reference's live graph, around d_1.conv1)."""
         flat, gflat, _ = self.model._flat
         if self.m is None or self.m.data_ptr() == 0 or self.m.numel() != flat.numel():
             self.m = torch.zeros_like(flat)
             self.v = torch.zeros_like(flat)
         self.step_count += 1
-        L, st = _lib.lib(), _lib.stream()
-        for a, b in self.trainable_ranges():                      # 2 launches for the reference's live graph (around d_1.conv1)
-            off = C.c_void_p
-            _lib.check(L.rdm_adamw_fused(off(flat.data_ptr() + 4 * a), off(gflat.data_ptr() + 4 * a), off(self.m.data_ptr() + 4 * a),
-                                         off(self.v.data_ptr() + 4 * a), b - a, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                         self.step_count, float(grad_scale), st))
+        if sync is not None and sync.world > 1:
+            self.sync, self.mode = sync, "per stage, as its reduction lands"
+            scale = 1.0 / sync.world
+            covered = []
+
+            def on_reduced(stage, ranges):
+                for a, b in ranges:
+                    self._update(a, b, scale)
+                covered.append(sync.slices[stage])
+            sync.finish(on_reduced=on_reduced)
+            # parameters outside every stage bucket (none for the reference's graph: the stages tile the stack) would be stale replicas
+            assert sum(b - a for a, b in covered) >= sum(b - a for a, b in self.trainable_ranges()), "backward stages do not cover the trainable parameters"
+        else:
+            for a, b in self.trainable_ranges():                  # 2 launches for the reference's live graph (around d_1.conv1)
+                self._update(a, b, grad_scale)
         self.model.mark_weights_changed()                         # derived bf16 copies are stale now
         self.small.step()
 
     def state_dict(self):
         """Moments, step and lr (the ``optimizer_states`` entry of a checkpoint)."""
+        if self.sync is not None and self.m is not None:          # "reduce_scatter": each rank holds the moments of its shards only
+            self.sync.allgather_shards(self.m)
+            self.sync.allgather_shards(self.v)
         return {"step": self.step_count, "lr": self.lr, "exp_avg": None if self.m is None else self.m.detach().cpu().clone(),
                 "exp_avg_sq": None if self.v is None else self.v.detach().cpu().clone(), "small": self.small.state_dict()}
 
@@ -164,7 +194,10 @@ def find_learning_rate(model, opt, batches, min_lr=1e-8, max_lr=1.0, num_trainin
         opt.zero_grad()
         loss, _ = training_step(model, x, y)
         loss.backward()
-        opt.step(grad_scale=sync.finish() if sync is not None else 1.0)
+        if sync is not None:
+            opt.step(sync=sync)
+        else:
+            opt.step()
         cur = float(loss.item())
         if sync is not None:
             # data parallel: the early stop below must be a COLLECTIVE decision.  Each rank's shard loss diverges at a different

@@ -52,7 +52,8 @@ def main(argv=None):
     parser = ArgumentParser("Trains mono depth estimation models (MI355X-native stack)")
     parser.add_argument("--seed", default=None, type=int)
     parser.add_argument("--precision", default=32, type=int, help="32 (default here - the parity configuration): float32 training and validation; 16 (the reference's default, AMP O2, train.py:11,57-58): training in the mixed-precision "
-                        "arithmetic mode (model.gemm_bf16 = 1: bf16 GEMM operands with float32 accumulation in dense_e2 / e3 / e4, float32 weights, statistics and optimiser) and the VALIDATION forward on the bf16 MFMA path")
+                        "arithmetic mode (model.gemm_bf16 = 3: bf16 operands with float32 accumulation in the GRADIENT GEMMs of the dense blocks; float32 forward, weights, statistics and optimiser) and the VALIDATION forward on the bf16 MFMA path")
+    parser.add_argument("--gemm_bf16", type=int, default=None, choices=[0, 1, 2, 3], help="explicit mixed-precision arithmetic mode of the training step: 1 forward + gradient GEMMs, 2 forward only, 3 gradient GEMMs only (what --precision 16 selects)")
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--dev", action="store_true", help="one train + one val step (Lightning fast_dev_run)")
     parser.add_argument("--overfit", action="store_true", help="reuse one batch")
@@ -103,7 +104,15 @@ def main(argv=None):
     from .metrics import MetricLogger
     from .network.RDM_Net import DepthEstimationNet
     model = DepthEstimationNet(relative_decoders=tuple(args.relative_decoders)).to(dev)
-    model.gemm_bf16 = 1 if args.precision == 16 else 0         # --precision 16: mixed-precision arithmetic for the training step (tolerance: tests/test_gpu_mixed.py)
+    # --precision 16 (the reference's default, train.py:11,57-58: fp16 AMP O2): mixed-precision ARITHMETIC for the training step.  Mode 3 =
+    # bf16 operands in the GRADIENT GEMMs only: logits identical to the f32 step, every gradient tensor's cosine >= 0.9999, loss after four
+    # AdamW steps within 0.1 % (tests/test_gpu_mixed.py).  Mode 1 (forward GEMMs rounded as well: logits RMS 3 %, gradient cosine down to
+    # 0.84 at the hash-filled initial point, no loss scaling or long-run convergence evidence) stays an explicit choice: --gemm_bf16 1.
+    model.gemm_bf16 = (args.gemm_bf16 if args.gemm_bf16 is not None else 3) if args.precision == 16 else (args.gemm_bf16 or 0)
+    # the reference trains on the GPU, where depth2label_sid of a non-positive depth (int(NaN)) is 0; the CPU semantics (0x80000000) are what
+    # the fixtures pin and stay the library default - training follows the reference's device
+    from . import utils as _u
+    _u.NAN_LABEL = "cuda"
     resumed = None
     if args.resume:
         from .checkpoint import from_lightning
@@ -167,7 +176,7 @@ def main(argv=None):
             opt.zero_grad()
             loss, parts = harness.training_step(model, x, y)
             loss.backward()
-            opt.step(grad_scale=sync.finish())
+            opt.step(sync=sync)                                  # per bucket as its reduction lands (one process: the plain update)
             if rank == 0:
                 print(f"epoch {epoch} step {it} loss {loss.item():.4f} MSE {parts['mse'].item():.4f} Ord_Loss {parts['ord_loss'].item():.4f} "
                       f"Fine_Detail {parts['fine_detail_loss'].item():.4f}", flush=True)

@@ -170,11 +170,12 @@ def run_net_goldens(RDM, cp, u, l, out):
     n_params = sum(p.numel() for p in model.parameters())
     print("params", n_params, "keys", len(keys))
 
-    taps = {}
+    taps, tapsub = {}, {}
 
     def hook(name):
         def fn(mod, inp, outp):
             taps[name] = stats3(outp)
+            tapsub[name] = filler.tap_subsample(outp.detach())        # element-wise values on a strided (pixel, channel) lattice
         return fn
 
     enc = model.encoder
@@ -210,6 +211,7 @@ def run_net_goldens(RDM, cp, u, l, out):
     g["train228_losses"] = np.array([r["mse"].item(), float(r["fine_detail_loss"]), r["ord_loss"].item(), r["loss_all"].item()])
     for k, v in taps.items():
         g[f"train228_tap_{k}"] = v
+        g[f"train228_tapsub_{k}"] = tapsub[k]
     names, gnorm, gsum, ghead = [], [], [], []
     for name, p in model.named_parameters():
         names.append(name)
@@ -249,6 +251,7 @@ def run_net_goldens(RDM, cp, u, l, out):
         g[f"eval226_yhat{i}"] = t.numpy()
     for k, v in taps.items():
         g[f"eval226_tap_{k}"] = v
+        g[f"eval226_tapsub_{k}"] = tapsub[k]
 
     # ---- (3) rectangular geometries: reference is defined up to the DORN head only ---
     #      (RDM_Net.py:73-103; decompose raises afterwards)
@@ -267,6 +270,7 @@ def run_net_goldens(RDM, cp, u, l, out):
     assert filler.dorn_unsafe_pairs(g["train228x304_logits"]) == 0, "train228x304 seed has near-tie ordinal pairs"
     for k, v in taps.items():
         g[f"train228x304_tap_{k}"] = v
+        g[f"train228x304_tapsub_{k}"] = tapsub[k]
     try:
         model(torch.from_numpy(xn))
         g["train228x304_full_forward_raises"] = np.array(0)

@@ -6,7 +6,9 @@ and weight, f32 accumulation, through 78 dense layers.  Against the float32 orac
   * logits:         max |d| <= 4 % of max |logits| and RMS(d) <= 1 % of RMS(logits)
   * probabilities:  mean |dP| <= 5e-3, max |dP| <= 0.15 (a 2-way softmax over a pair of logits a few percent apart)
   * ordinal counts: every pixel within +-3 of the reference count, mean |d count| <= 0.5
-and against the f32 HIP path at the BASELINE size (B=8, 228x304) the same bounds + per-sample independence.
+and at the BASELINE size (B=8, 228x304) and the KITTI geometry the same bounds against the ORACLE's eval-mode float32 forward on the
+same batch (the CPU restatement pinned by the reference's fixtures - not the product's own f32 path, which is only a second witness
+there) + per-sample independence.
 Op level (no accumulation through depth): the bf16 kernels reproduce a torch f32 reference fed the SAME bf16-rounded operands to
 2e-3 of the output's max (f32 accumulation, one rounding of the result)."""
 import ctypes as C
@@ -17,9 +19,17 @@ import torch
 import torch.nn.functional as F
 
 from md_rdm_amd import filler
+from oracle import rdm_net_cpu as onet
 
 pytestmark = pytest.mark.gpu
 U = filler.uniform
+
+
+def oracle_eval_forward(x):
+    """(decode, P, logits) of the oracle's eval-mode float32 forward (oracle/rdm_net_cpu.py, pinned by tests/test_oracle_net.py)."""
+    with torch.no_grad():
+        _, dec, P, lg = onet.forward(onet.new_state_dict(filler.state_value), torch.from_numpy(x), training=False)
+    return np.asarray(dec), np.asarray(P), np.asarray(lg)
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +80,9 @@ def test_bf16_b8_228x304_vs_f32_path_and_sample_independence(dev):
         lg = m._native_forward_bf16(xg).cpu().numpy()
         _, dec1, P1 = m(xg[5:6].contiguous())
     assert tuple(P.shape) == (B, 90, 8, 10) and torch.isfinite(P).all()
-    head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, dec32.cpu().numpy(), P32.cpu().numpy(), lg32)
+    odec, oP, olg = oracle_eval_forward(x)                      # BASELINE configs[1] against the ORACLE, whole batch (~10 s of CPU)
+    head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, odec, oP, olg)
+    head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, dec32.cpu().numpy(), P32.cpu().numpy(), lg32)      # second witness: the f32 HIP path
     assert torch.equal(dec, (P > 0.5).sum(1, keepdim=True))
     # eval BatchNorm: samples do not interact.  A batch of 1 takes other tiles / K-splits (another summation order, other bf16
     # roundings), so a sample alone agrees with itself in the batch to bf16 noise, not bit for bit ...
@@ -94,6 +106,8 @@ def test_bf16_kitti_geometry_352x1216_vs_f32_path(dev):
         m.set_precision("bf16")
         _, dec, P = m(xg)
         lg = m._native_forward_bf16(xg).cpu().numpy()
+    odec, oP, olg = oracle_eval_forward(x)
+    head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, odec, oP, olg)
     head_bounds(dec.cpu().numpy(), P.cpu().numpy(), lg, dec32.cpu().numpy(), P32.cpu().numpy(), lg32)
 
 

@@ -1,9 +1,11 @@
 """-m gpu: DepthEstimationNet on the native plan vs (a) the fixtures produced by RUNNING the
 reference and (b) the oracle on the same seeded inputs.
 
-Forward tolerance: 1e-4 relative (north star), written as atol = 2e-4*max|ref| on logits / 2e-4 on
-probabilities; ordinal indices BIT-EXACT, asserted outright: the fixture inputs (filler.MARGIN_SEEDS)
-were chosen so that every ordinal pair decision of the reference has a margin of 25x the f32 conv noise.
+Forward tolerance: the north star's 1e-4 relative, ELEMENT-WISE: the HIP logits against the reference's logits at
+atol = 1e-4 * max|ref|, the ordinal probabilities at 1e-4, every block tap on a strided (pixel, channel) lattice
+(filler.tap_subsample, ~3 K values per tap stored by make_golden.py) at 1e-4 * max|tap|; ordinal indices BIT-EXACT,
+asserted outright: the fixture inputs (filler.MARGIN_SEEDS) were chosen so that every ordinal pair decision of the
+reference has a margin of 25x the f32 conv noise.
 Backward: the loss surface is piecewise linear (ReLU, clamp); at B=2 the reference's own float32
 gradients deviate from a float64 evaluation by up to ~10 % on some tensors because single ReLU
 decisions flip (tests/test_oracle_net.py::test_f32_gradient_noise_floor documents it on CPU).  The
@@ -19,6 +21,42 @@ from oracle import rdm_net_cpu as onet
 
 pytestmark = pytest.mark.gpu
 TAPS = {"max_e1": ("blk0", 96), "dense_e2": ("blk0", 384), "dense_e3": ("blk1", 768), "dense_e4": ("blk2", 2112), "d1_dense": ("blk3", 2208)}
+# element-wise taps: the block outputs above + the transition outputs (= the first channels of the next block's buffer)
+SUBTAPS = dict(TAPS, trans_e2=("blk1", 192), trans_e3=("blk2", 384), trans_e4=("blk3", 1056))
+CTOT = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}
+REL = 1e-4                                                     # BASELINE.json north_star: "1e-4 relative float tolerance"
+
+
+def check_taps(m, gold, prefix):
+    """Every tap, element-wise on the fixture's lattice, at 1e-4 of the tap's maximum (+ the three summary statistics as before)."""
+    for tap, (buf, c) in SUBTAPS.items():
+        v = m.debug_buffer(buf).view(-1, CTOT[buf])[:, :c]
+        ref = gold[f"{prefix}_tapsub_{tap}"]
+        got = filler.tap_subsample(v)
+        assert got.shape == ref.shape, (tap, got.shape, ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=REL * np.abs(ref).max(), err_msg=tap)
+        if tap in TAPS:
+            np.testing.assert_allclose(stats3(v), gold[f"{prefix}_tap_{tap}"], rtol=1e-4, atol=1e-6)
+
+
+def check_taps_vs_oracle(m, taps):
+    """The same element-wise lattice against the ORACLE's taps of the same input (oracle/rdm_net_cpu.py fills taps["sub_<tap>"])."""
+    for tap, (buf, c) in SUBTAPS.items():
+        v = m.debug_buffer(buf).view(-1, CTOT[buf])[:, :c]
+        ref = taps["sub_" + tap]
+        np.testing.assert_allclose(filler.tap_subsample(v), ref, rtol=0, atol=REL * np.abs(ref).max(), err_msg=tap)
+        if tap in TAPS:
+            np.testing.assert_allclose(stats3(v), taps[tap], rtol=1e-4, atol=1e-6, err_msg=tap)
+
+
+def check_logits_vs_oracle(m, ref_nchw):
+    ref = np.transpose(np.asarray(ref_nchw), (0, 2, 3, 1)).reshape(-1, ref_nchw.shape[1])
+    np.testing.assert_allclose(hip_logits(m), ref, rtol=0, atol=REL * np.abs(ref).max())
+
+
+def hip_logits(m):
+    """(pixels, 180) logits of the last forward (the d_1.conv2 output the DORN head consumes; rows of 192 in the plan)."""
+    return m.debug_buffer("logits").view(-1, 192)[:, :180].cpu().numpy()
 
 
 def stats3(t):
@@ -45,10 +83,13 @@ def make_model(dev, train=True, deterministic=False):
 SEED = filler.MARGIN_SEEDS
 
 
-def check_head(dec, P, gold_dec, gold_P, gold_logits):
+def check_head(dec, P, gold_dec, gold_P, gold_logits, logits=None):
     assert filler.dorn_unsafe_pairs(gold_logits) == 0          # the fixture was built with margins (make_golden.py refuses otherwise)
     np.testing.assert_array_equal(dec, gold_dec)               # ordinal indices: bit-exact, everywhere
-    np.testing.assert_allclose(P, gold_P, atol=2e-4)
+    np.testing.assert_allclose(P, gold_P, rtol=0, atol=REL)
+    if logits is not None:                                     # the conv stack's output itself, element by element (reference: NCHW)
+        ref = np.transpose(gold_logits, (0, 2, 3, 1)).reshape(-1, gold_logits.shape[1])
+        np.testing.assert_allclose(logits, ref, rtol=0, atol=REL * np.abs(ref).max())
 
 
 def test_train_step_vs_reference_goldens(dev, net_gold):
@@ -56,12 +97,9 @@ def test_train_step_vs_reference_goldens(dev, net_gold):
     m = make_model(dev)
     x, y = filler.synthetic_batch(2, 228, 228, seed=SEED["train228"])
     loss, parts = harness.training_step(m, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
-    for tap, (buf, c) in TAPS.items():
-        v = m.debug_buffer(buf)
-        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
-        np.testing.assert_allclose(stats3(v.view(-1, ctot)[:, :c]), net_gold[f"train228_tap_{tap}"], rtol=1e-4, atol=1e-6)
+    check_taps(m, net_gold, "train228")
     dec, P = parts["ord_depth_pred"].cpu().numpy(), parts["ord_label_pred"].detach().cpu().numpy()
-    check_head(dec, P, net_gold["train228_decode_c"], net_gold["train228_ord_labels"], net_gold["train228_logits"])
+    check_head(dec, P, net_gold["train228_decode_c"], net_gold["train228_ord_labels"], net_gold["train228_logits"], hip_logits(m))
     np.testing.assert_array_equal(parts["ord_y"].cpu().numpy(), net_gold["train228_ord_y"])
     for i in range(4):   # atol: log-domain values near log(1)=0 inherit the reference's own f32 geometric-mean rounding
         np.testing.assert_allclose(parts["fine_details"][i].detach().cpu().numpy(), net_gold[f"train228_yhat{i}"], rtol=1e-4, atol=5e-6)
@@ -89,8 +127,8 @@ def test_eval_forward_226_vs_reference(dev, net_gold):
     x, _ = filler.synthetic_batch(1, 226, 226, seed=SEED["eval226"])
     with torch.no_grad():
         yh, dec, P = m(torch.from_numpy(x).to(dev))
-    check_head(dec.cpu().numpy(), P.cpu().numpy(), net_gold["eval226_decode_c"], net_gold["eval226_ord_labels"], net_gold["eval226_logits"])
-    np.testing.assert_allclose(stats3(m.debug_buffer("blk3")), net_gold["eval226_tap_d1_dense"], rtol=1e-4, atol=1e-6)
+    check_head(dec.cpu().numpy(), P.cpu().numpy(), net_gold["eval226_decode_c"], net_gold["eval226_ord_labels"], net_gold["eval226_logits"], hip_logits(m))
+    check_taps(m, net_gold, "eval226")
     for i in range(4):
         np.testing.assert_allclose(yh[i].cpu().numpy(), net_gold[f"eval226_yhat{i}"], rtol=1e-4, atol=5e-6)
 
@@ -101,10 +139,8 @@ def test_rectangular_228x304_head_vs_reference(dev, net_gold):
     with torch.no_grad():
         yh, dec, P = m(torch.from_numpy(x).to(dev))
     assert dec.shape == (2, 1, 8, 10)
-    check_head(dec.cpu().numpy(), P.cpu().numpy(), net_gold["train228x304_decode_c"], net_gold["train228x304_ord_labels"], net_gold["train228x304_logits"])
-    for tap, (buf, c) in TAPS.items():
-        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
-        np.testing.assert_allclose(stats3(m.debug_buffer(buf).view(-1, ctot)[:, :c]), net_gold[f"train228x304_tap_{tap}"], rtol=1e-4, atol=1e-6)
+    check_head(dec.cpu().numpy(), P.cpu().numpy(), net_gold["train228x304_decode_c"], net_gold["train228x304_ord_labels"], net_gold["train228x304_logits"], hip_logits(m))
+    check_taps(m, net_gold, "train228x304")
     assert [tuple(t.shape) for t in yh] == [(2, 1, 1, 1), (2, 1, 2, 2), (2, 1, 4, 4), (2, 1, 8, 8)]      # documented generalisation
 
 
@@ -286,7 +322,7 @@ def test_fused_adamw_leaves_frozen_encoder_bit_identical(dev):
 def test_train_step_b16_228x304_vs_oracle(dev):
     """The BENCH geometry itself (BASELINE configs[2]: B=16, 228x304, full train step) against the CPU oracle on the same seeded
     batch - the step that selects the split-precision gradient kernels of dense_e2 / e3, the 256-pixel halo tiles and conv1x1_dma256_kernel.  Forward: block taps
-    rtol 1e-4, logits 2e-4 of their max, probabilities 2e-4, losses 1e-4, ordinal indices equal wherever the oracle's decision has
+    rtol 1e-4 + element-wise lattice at 1e-4 of the tap's max, logits element-wise at 1e-4 of their max, probabilities 1e-4, losses 1e-4, ordinal indices equal wherever the oracle's decision has
     the +-2.5e-4 margin (this input was not margin-searched; the unsafe pairs are counted and bounded).  Backward: the per-tensor
     criterion of the B=2 test - relative L2 error against the float64 oracle <= 2 x that tensor's own float32-oracle error + 1.5e-2,
     gradient norm against the float64 oracle's <= 3 x the float32 oracle's own norm error + 1.5e-3 (or the geometric bound)."""
@@ -302,12 +338,11 @@ def test_train_step_b16_228x304_vs_oracle(dev):
     taps = {}
     r32 = onet.training_step(onet.new_state_dict(filler.state_value), torch.from_numpy(x), y, taps=taps)
     t1 = time.time()
-    for tap, (buf, c) in TAPS.items():
-        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
-        np.testing.assert_allclose(stats3(m.debug_buffer(buf).view(-1, ctot)[:, :c]), taps[tap], rtol=1e-4, atol=1e-6, err_msg=tap)
+    check_taps_vs_oracle(m, taps)
+    check_logits_vs_oracle(m, r32["logits"])
     P = parts["ord_label_pred"].detach().cpu().numpy()
     dec = parts["ord_depth_pred"].cpu().numpy()
-    np.testing.assert_allclose(P, r32["P"], atol=2e-4)
+    np.testing.assert_allclose(P, r32["P"], rtol=0, atol=REL)
     safe = filler.dorn_safe_mask(r32["logits"])                                # pair decisions that survive +-2.5e-4 on both logits
     assert safe.mean() > 0.99
     np.testing.assert_array_equal(((P > 0.5) & safe).sum(1, keepdims=True), ((r32["P"] > 0.5) & safe).sum(1, keepdims=True))
@@ -382,7 +417,7 @@ def test_full_size_properties_b16_228x304(dev):
 
 def test_kitti_train_step_b2_352x1216_vs_oracle(dev):
     """BASELINE configs[4]'s geometry (352x1216: 88x304 / 44x152 / 22x76 / 11x38 maps; the Winograd kernels at 53 504 and 13 376 pixels, the
-    direct ones below) as a train step against the CPU oracle at B=2: block taps 1e-4, probabilities 2e-4, ordinal indices equal wherever the
+    direct ones below) as a train step against the CPU oracle at B=2: block taps and logits element-wise at 1e-4 of their maximum, probabilities 1e-4, ordinal indices equal wherever the
     oracle's pair decision has the margin, the ordinal loss 1e-4, every gradient tensor to the ReLU-flip noise level of a float32 evaluation
     (relative L2 <= 4e-2 against the oracle's float32 gradients, their norms within 2e-2)."""
     from md_rdm_amd import harness
@@ -394,12 +429,11 @@ def test_kitti_train_step_b2_352x1216_vs_oracle(dev):
     torch.cuda.synchronize()
     taps = {}
     r32 = onet.training_step(onet.new_state_dict(filler.state_value), torch.from_numpy(x), y, taps=taps)
-    for tap, (buf, c) in TAPS.items():
-        ctot = {"blk0": 384, "blk1": 768, "blk2": 2112, "blk3": 2208}[buf]
-        np.testing.assert_allclose(stats3(m.debug_buffer(buf).view(-1, ctot)[:, :c]), taps[tap], rtol=1e-4, atol=1e-6, err_msg=tap)
+    check_taps_vs_oracle(m, taps)
+    check_logits_vs_oracle(m, r32["logits"])
     P = parts["ord_label_pred"].detach().cpu().numpy()
     assert P.shape == (B, 90, 11, 38)
-    np.testing.assert_allclose(P, r32["P"], atol=2e-4)
+    np.testing.assert_allclose(P, r32["P"], rtol=0, atol=REL)
     safe = filler.dorn_safe_mask(r32["logits"])
     np.testing.assert_array_equal(((P > 0.5) & safe).sum(1, keepdims=True), ((r32["P"] > 0.5) & safe).sum(1, keepdims=True))
     np.testing.assert_allclose(parts["ord_loss"].item(), r32["ord_loss"], rtol=1e-4)
