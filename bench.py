@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--backward-precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="bf16x3 (default, what the package ships): the gradient GEMMs of dense_e2 / dense_e3 on the split-precision kernels; f32: exact-f32 MFMA everywhere")
     ap.add_argument("--forward-split", type=int, default=1, help="1 (default, what the package ships): conv1 of dense_e2 / e3 on the three-way-split bf16x6 forward kernel (float32-equivalent); 0: f32 MFMA")
+    ap.add_argument("--split-rows", type=int, default=1, help="1 (default, what the package ships): dY and relu1(norm1(x)) reach the split conv1 gradient kernels as split rows written once by their producers; 0: each kernel converts and splits per tile (A/B)")
+    ap.add_argument("--wino-x6", type=int, default=1, help="1 (default, what the package ships): conv2 of dense_e2 / e3 forward as Winograd on three-way-split bf16 MFMAs; 0: the f32 MFMA Winograd kernel (A/B)")
     ap.add_argument("--gemm-bf16", type=int, default=0, choices=[0, 1, 2, 3],
                     help="MIXED-PRECISION arithmetic (the reference's default --precision 16): the GEMMs the two options above route to the split kernels round their operands to bf16, "
                     "one MFMA per product. 1: forward and gradient GEMMs, 2: forward only, 3: gradient GEMMs only. NOT the parity configuration - a separately labelled line, never the headline")
@@ -247,6 +249,8 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
     model.backward_precision = args.backward_precision
     model.forward_split = bool(args.forward_split)
     model.gemm_bf16 = int(args.gemm_bf16)
+    model.split_rows = bool(args.split_rows)
+    model.wino_x6 = bool(args.wino_x6)
     filler.fill_state_dict(model.state_dict())
     model = model.to(dev)
     model.train()
@@ -312,10 +316,12 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
         # what each kernel family EXECUTES on the matrix pipe per algorithmic FLOP: the Winograd kernels (kinds 9, 10) multiply 1 / 2.25 as
         # much on the f32 pipe; the split-precision kernels (13-16) run three bf16 MFMAs per product on the bf16 pipe
         def pipe_of(kind):
+            if kind == 18:                                      # Winograd on the bf16 pipe: 6 products per float32 product, 1 / 2.25 of the direct FLOPs
+                return ("bf16", 6.0 / 2.25, PEAK_BF16)
             return ("bf16", (1.0 if args.gemm_bf16 in (1, 2) else 6.0) if kind == 17 else (1.0 if args.gemm_bf16 in (1, 3) else 3.0), PEAK_BF16) if kind >= 13 else ("f32", 1.0 / 2.25 if kind in (9, 10) else 1.0, PEAK_F32)
         per_kernel, busy_ms = [], 0.0
         executed_f32 = executed_bf16 = 0.0
-        for kind in list(range(11)) + [13, 14, 15, 16, 17]:
+        for kind in list(range(11)) + [13, 14, 15, 16, 17, 18]:
             nm, kms, kfl, kn = C.c_char_p(), C.c_double(), C.c_double(), C.c_int32()
             _lib.check(L.rdm_profile_kind(kind, C.byref(nm), C.byref(kms), C.byref(kfl), C.byref(kn)))
             if kn.value:

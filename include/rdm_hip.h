@@ -48,7 +48,7 @@ int rdm_version(void);
  * and clears the record. */
 void rdm_profile_enable(int32_t on);
 int rdm_profile_read(double* conv_ms_sum, double* conv_ms_union, double* conv_flops, int32_t* launches);
-/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..16 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-5 the direct f32 MFMA kernels, 13-16 the split-precision bf16x3 gradient kernels - FLOPs = the float32 product's, i.e. algorithmic,
+/* Per-kernel breakdown of the LAST rdm_profile_read(): kind = 0..18 (returns RDM_ERR_BAD_ARGUMENT beyond; 0-5 the direct f32 MFMA kernels, 13-16 the split-precision bf16x3 gradient kernels - FLOPs = the float32 product's, i.e. algorithmic,
  * 7-8 and 11-12 the bf16 forward kernels, 9-10 the Winograd f32 forward / weight-gradient kernels - their FLOPs are the DIRECT convolution's, i.e. algorithmic), *name = static string naming the kernel, summed duration (ms), executed FLOPs and launch count. */
 int rdm_profile_kind(int32_t kind, const char** name, double* ms_sum, double* flops, int32_t* launches);
 /* algorithmic HBM bytes (operands read once + result written once) of those launches; kept for the bf16 kernels (0 for the f32 kinds) */
@@ -129,6 +129,17 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * (1x1: 96 <= in_c <= 2304, in_c a multiple of 48; 3x3 / stride 1 / pad 1: out_c <= 48, rows of <= 93 pixels). */
 /* `products` (all four entry points): bf16 MFMAs per float32 product - 0 = the split arithmetic (3; 6 for the forward), 1 = operands simply ROUNDED to
  * bf16 (one MFMA, float32 accumulation): the arithmetic of a mixed-precision (AMP) step, ~2e-3 of the result's maximum; RDM_NET_OPT_GEMM_BF16. */
+/* SPLIT ROWS (round 5): a float32 row of C values (C a multiple of 4) stored in the same 4 C bytes as, per four consecutive values,
+ * [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] bf16 (hi = bf16(x), lo = bf16(x - hi)) - the two halves the split kernels feed their MFMAs.  An operand handed
+ * over in this form is staged verbatim: its conversion is paid once by the producer (rdm_split_rows_f32; rdm_bn_bwd with accumulate = 2) instead of
+ * once per consumer tile.  OR these flags into `products` (split arithmetic only, 1x1 kernels only): the output-gradient operand `dy` / the
+ * activation operand `x` (then already activated: bn_scale = bn_shift = NULL) is given as split rows. */
+#define RDM_X3_DY_SPLIT_ROWS 0x10
+#define RDM_X3_X_SPLIT_ROWS 0x20
+/* dst (split rows, row stride dst_ld floats' worth of bytes) = split(ReLU(bn_scale * src + bn_shift)), or split(src) with bn_scale = bn_shift = NULL:
+ * relu1(norm1(x)) of a dense layer (torchvision _DenseLayer reached from network/RDM_Net.py:526-530) as the operand of its conv1 weight gradient. */
+int rdm_split_rows_f32(const float* src, int32_t src_ld, const float* bn_scale, const float* bn_shift, void* dst, int32_t dst_ld, int64_t rows,
+                       int32_t channels, rdm_stream_t stream);
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift,
                         float* dw_packed, int32_t split_k, int32_t products, rdm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 input gradient with out_c = 48 (the dense layers' conv2): operands and meaning of rdm_conv2d_dgrad (gate + BatchNorm-backward
@@ -158,6 +169,13 @@ size_t rdm_conv3x3_wino_workspace_bytes(int32_t channels, int32_t batch, int32_t
 int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
                          double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream);
 
+/* The same convolution on the bf16 matrix pipe with float32-EQUIVALENT arithmetic (round 5): both transformed operands split three ways
+ * (v = v0 + v1 + v2 in bf16, 24 significant bits), six bf16 products per float32 product, float32 accumulation - the arithmetic of
+ * rdm_conv1x1_fwd_x6 applied to the 16 position GEMMs of F(2x2, 3x3).  Same operands, meaning and tolerance as rdm_conv3x3_wino_fwd
+ * (tests/test_gpu_wino.py holds both to 2e-5 of the output's maximum against float64); ~2x its speed at dense_e2 / dense_e3 sizes. */
+size_t rdm_conv3x3_wino_x6_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k);
+int rdm_conv3x3_wino_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
+                            double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream);
 /* ... and the weight gradient of that convolution as Winograd F(3x3, 2x2): same operands and meaning as rdm_conv2d_wgrad (BatchNorm + ReLU
  * prologue on x), except that dw_packed [9][out_c][in_c] is WRITTEN, not accumulated, and that the K-split partial sums are combined
  * in a fixed order (no atomics: bit-reproducible).  The workspace holds the transformed gradient and the per-split partial sums. */
@@ -229,7 +247,8 @@ int rdm_bn_finalize(const double* sum, const double* sumsq, double count, const 
 int rdm_bn_bwd_reduce(float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const float* scale, const float* shift, int64_t rows,
                       int32_t channels, double* sum_dz, double* sum_dz_x, rdm_stream_t stream);
 /* BatchNorm backward from the reductions: dx (=|+= when accumulate) gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) in training,
- * gamma*rstd*dz in eval; dgamma[c] = sum dz*xhat, dbeta[c] = sum dz (either may be NULL). */
+ * gamma*rstd*dz in eval; dgamma[c] = sum dz*xhat, dbeta[c] = sum dz (either may be NULL).  accumulate: 0 = write, 1 = add, 2 = write dx as
+ * SPLIT ROWS (see rdm_split_rows_f32): the form in which the norm2 backward hands dY to the split-precision conv1 gradient kernels. */
 int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const double* sum_dz,
                const double* sum_dz_x, double count, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
                float* dbeta, int64_t rows, int32_t channels, int32_t accumulate, int32_t training, rdm_stream_t stream);
@@ -306,6 +325,11 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *   RDM_NET_OPT_PREPACK          (default 1) the weight images of the split kernels (three-way split for the 1x1 forward, fragment order / transposed split
  *                                for the two input-gradient kernels) are formed for ALL layers once per training step on the library's side stream at the
  *                                start of rdm_net_forward, instead of by one small launch in front of every kernel on the dependent chain.
+ *   RDM_NET_OPT_SPLIT_ROWS       (default 1) float32 arithmetic on the split kernels: the norm2 BatchNorm backward writes dY as split rows and relu1(norm1(x))
+ *                                is activated + split once per layer (rdm_split_rows_f32) - the conv1 input / weight gradient kernels stage both operands
+ *                                verbatim instead of converting and splitting them per tile.  Bit-identical gradients (the same two bf16 values per element).
+ *   RDM_NET_OPT_WINO_X6          (default 1, with RDM_NET_OPT_SPLIT_FWD) the Winograd 3x3 forward of the blocks with >= 8 192 pixels runs the bf16x6 kernel
+ *                                (rdm_conv3x3_wino_fwd_x6: float32-equivalent accuracy on the bf16 matrix pipe) instead of the f32 MFMA one.
  *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic (the reference's default --precision 16, train.py:11,57-58): every launch that
  *                                RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels rounds its operands to bf16 instead (ONE bf16
  *                                MFMA per product, float32 accumulation).  value 1 = forward and gradient GEMMs, 2 = forward only, 3 = gradient GEMMs
@@ -313,7 +337,7 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                GEMMs in this mode the per-layer dZ -> dY scratch tensor is kept as bf16.  Not the parity configuration: tolerance
  *                                stated in tests/test_gpu_mixed.py. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9, RDM_NET_OPT_PREPACK = 10 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9, RDM_NET_OPT_PREPACK = 10, RDM_NET_OPT_SPLIT_ROWS = 11, RDM_NET_OPT_WINO_X6 = 12 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "rdm_conv3x3_dgrad_x3_workspace_bytes": (sz, [i32]),
     "rdm_conv3x3_dgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_wino_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "rdm_conv3x3_wino_x6_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "rdm_conv3x3_wino_fwd_x6": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_wino_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]),
     "rdm_conv3x3_wino_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "rdm_conv3x3_wino_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -107,6 +109,7 @@ _SIGNATURES = {
     "rdm_fine_detail_pred_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "rdm_candidates_matvec_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
     "rdm_candidates_matvec_bwd": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
+    "rdm_split_rows_f32": (C.c_int, [vp, i32, vp, vp, vp, i32, i64, i32, vp]),
     "rdm_layout_nchw_to_nhwc_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "rdm_layout_nhwc_to_nchw_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, vp]),
     "rdm_recombine_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

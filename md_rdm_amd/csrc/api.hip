@@ -252,7 +252,10 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
   RDM_CHECK_ARG(dy && w && dx, "conv1x1_dgrad_x3: NULL operand");
+  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0;
+  products &= ~RDM_X3_DY_SPLIT_ROWS;
   RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv1x1_dgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
+  RDM_CHECK_ARG(!dy_rows || products != 1, "conv1x1_dgrad_x3: split rows are an operand of the split arithmetic (products 0 / 3)");
   RDM_CHECK_ARG(!mask_x || (mask_scale && mask_shift && stat_a && stat_b), "conv1x1_dgrad_x3: mask needs scale, shift and both statistics");
   ConvGeom gd{d->batch, g.Ho, g.Wo, d->in_h, d->in_w, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, -1};
   FwdArgs a{};
@@ -260,6 +263,7 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
+  a.a_split = dy_rows;
   if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 2304)"); return RDM_ERR_UNSUPPORTED; }
   return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream, products == 1 ? 1 : 3);
 }
@@ -267,7 +271,11 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
                         int32_t split_k, int32_t products, rdm_stream_t stream) {
   RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad_x3: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
+  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0, x_rows = (products & RDM_X3_X_SPLIT_ROWS) != 0;
+  products &= ~(RDM_X3_DY_SPLIT_ROWS | RDM_X3_X_SPLIT_ROWS);
   RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv2d_wgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
+  RDM_CHECK_ARG(!(dy_rows || x_rows) || (products != 1 && d->kh == 1 && d->kw == 1), "conv2d_wgrad_x3: split rows are operands of the 1x1 kernel in the split arithmetic (products 0 / 3)");
+  RDM_CHECK_ARG(!x_rows || (bn_scale == nullptr && bn_shift == nullptr), "conv2d_wgrad_x3: split activation rows are already activated (rdm_split_rows_f32 applied BatchNorm + ReLU)");
   ConvGeom g;
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
@@ -279,6 +287,7 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.split_k = split_k;
   a.xsplit = products == 1 ? 1 : 3;
+  a.g_split = dy_rows; a.x_split = x_rows;
   if (d->kh == 1 && d->kw == 1) return launch_xs_wgrad1x1(a, stream);
   if (d->kh == 3 && d->kw == 3) return launch_xs_wgrad3x3(a, stream);
   set_error("conv2d_wgrad_x3: no split-precision kernel for a %dx%d convolution", d->kh, d->kw);
@@ -309,6 +318,37 @@ int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w,
   if ((rc = launch_wino_weight(w, (long)d->out_c * d->in_c, d->in_c, d->out_c, d->in_c, U, stream))) return rc;
   WinoConv a{};
   a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift; a.U = U;
+  a.out = y; a.ldc = d->out_ld; a.N = d->out_c; a.B = d->batch; a.H = d->in_h; a.W = d->in_w;
+  a.split = split_k; a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ub); a.partial_floats = (workspace_bytes - ub) / sizeof(float);
+  if (a.partial_floats < (size_t)M * 48 * 2) { a.partial = nullptr; a.partial_floats = 0; }
+  a.stat0 = stat_sum; a.stat1 = stat_sq;
+  return launch_conv3x3_wino_fwd(a, stream);
+}
+
+size_t rdm_conv3x3_wino_x6_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k) {
+  if (channels <= 0 || channels % 16 || batch <= 0 || h <= 0 || w <= 0 || split_k < 0) return 0;
+  const int T = batch * ((h + 1) / 2) * ((w + 1) / 2);
+  const int split = split_k > 0 ? split_k : wino_pick_split(T, channels / 16, true);
+  return wino_fwd_workspace_bytes(channels, (long)batch * h * w, split, true);
+}
+
+int rdm_conv3x3_wino_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y,
+                            double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream) {
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(x && w && y && workspace, "conv3x3_wino_fwd_x6: NULL operand");
+  RDM_CHECK_ARG(d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1, "conv3x3_wino_fwd_x6: 3x3 / stride 1 / pad 1 only");
+  RDM_CHECK_ARG(d->out_c <= 48 && d->in_c % 16 == 0, "conv3x3_wino_fwd_x6: out_c (%d) <= 48 and in_c (%d) a multiple of 16", d->out_c, d->in_c);
+  RDM_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr) && (stat_sum == nullptr) == (stat_sq == nullptr), "conv3x3_wino_fwd_x6: scale/shift and the two statistics go together");
+  RDM_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && split_k >= 0, "conv3x3_wino_fwd_x6: workspace must be 256-byte aligned, split_k >= 0");
+  const long M = (long)d->batch * d->in_h * d->in_w;
+  const size_t ub = (wino_u_bytes(d->in_c, true) + 255) & ~(size_t)255;
+  if (workspace_bytes < ub) { set_error("conv3x3_wino_fwd_x6: workspace too small: %zu < %zu", workspace_bytes, ub); return RDM_ERR_WORKSPACE_TOO_SMALL; }
+  float* U = static_cast<float*>(workspace);
+  if ((rc = launch_wino_weight(w, (long)d->out_c * d->in_c, d->in_c, d->out_c, d->in_c, U, stream, true))) return rc;
+  WinoConv a{};
+  a.A = x; a.lda = d->in_ld; a.C = d->in_c; a.a_scale = bn_scale; a.a_shift = bn_shift; a.U = U; a.x6 = 1;
   a.out = y; a.ldc = d->out_ld; a.N = d->out_c; a.B = d->batch; a.H = d->in_h; a.W = d->in_w;
   a.split = split_k; a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ub); a.partial_floats = (workspace_bytes - ub) / sizeof(float);
   if (a.partial_floats < (size_t)M * 48 * 2) { a.partial = nullptr; a.partial_floats = 0; }
@@ -462,8 +502,9 @@ int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const f
   if (int rc = check_nhwc(dz, dz_ld, channels, "bn_bwd(dz)")) return rc;
   if (int rc = check_nhwc(x, x_ld, channels, "bn_bwd(x)")) return rc;
   RDM_CHECK_ARG(sum_dz && sum_dz_x && gamma && save_mean && save_rstd && rows > 0 && rows < (1L << 31) && count >= 1, "bn_bwd: bad argument");
+  RDM_CHECK_ARG(accumulate >= 0 && accumulate <= 2, "bn_bwd: accumulate (%d) must be 0 (write), 1 (add) or 2 (write as split rows)", (int)accumulate);
   return launch_bn_bwd_apply(dx, dx_ld, dz, dz_ld, x, x_ld, sum_dz, sum_dz_x, count, gamma, save_mean, save_rstd, dgamma, dbeta, (int)rows, channels,
-                             accumulate != 0, training, stream);
+                             accumulate == 1, training, stream, false, accumulate == 2);
 }
 
 int rdm_maxpool3s2_fwd(const float* x, float* y, int32_t y_ld, uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t channels,
@@ -521,6 +562,12 @@ int rdm_padavgpool2_bwd(const float* dpooled, const float* x, int32_t x_ld, cons
   const double count = (double)batch * (h + 1) * (w + 1);
   if ((rc = launch_bn_bwd_coeffs(s0, s1, count, gamma, save_mean, save_rstd, cA, cB, cC, dgamma, dbeta, channels, training, stream))) return rc;
   return launch_trans_pool_bwd_apply(dpooled, x, x_ld, scale, shift, cA, cB, cC, dx, dx_ld, batch, h, w, channels, stream);
+}
+
+int rdm_split_rows_f32(const float* src, int32_t src_ld, const float* bn_scale, const float* bn_shift, void* dst, int32_t dst_ld, int64_t rows, int32_t channels,
+                       rdm_stream_t stream) {
+  RDM_CHECK_ARG(src && dst && rows > 0 && channels > 0 && src_ld >= channels && dst_ld >= channels, "split_rows: bad argument");
+  return launch_split_rows(src, src_ld, bn_scale, bn_shift, dst, dst_ld, rows, channels, stream);
 }
 
 int rdm_layout_nchw_to_nhwc_f32(const float* src, float* dst, int32_t dst_ld, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream) {

@@ -20,7 +20,9 @@ int launch_bn_bwd_defer(float* G, int ldg, const float* x, int ldx, const double
                         int slice_c0, int slice_n, int training, hipStream_t s);
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
-                        int training, hipStream_t s, bool bf16_rows = false);
+                        int training, hipStream_t s, bool bf16_rows = false, bool split_rows = false);
+// dst (split rows, xsplit_dev.h; row stride ld_dst in floats) = split(ReLU(scale * src + shift)) - or split(src) without scale / shift
+int launch_split_rows(const float* src, int ld_src, const float* scale, const float* shift, void* dst, int ld_dst, long M, int C, hipStream_t s);
 int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t s);
 int launch_trans_pool(const float* X, int ldx, const float* sc, const float* sh, float* P, int B, int H, int W, int C, hipStream_t s);
 int launch_trans_pool_bwd_reduce(const float* dP, const float* X, int ldx, const float* sc, const float* sh, int B, int H, int W, int C,

@@ -5,6 +5,7 @@
 // torchvision _DenseLayer BatchNorm2d (third party), network/module.py:41 (AdamW).
 #include "rdm_common.h"
 #include "elementwise.h"
+#include "xsplit_dev.h"
 
 namespace rdm {
 
@@ -294,12 +295,15 @@ int launch_zero_rows(float* p, long rows, long row_floats, long ld, hipStream_t 
 // x (1/count) instead of eight f64 divisions per thread, and half as many, longer workgroups.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+typedef float f32x4e __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
 
 // BF (mixed-precision arithmetic mode, RDM_NET_OPT_GEMM_BF16): dz and dst are bf16 rows (ldz / ldd in ELEMENTS of that type) - the consumers of dst
 // (the 1x1 dgrad / wgrad on bf16 operands) round it to bf16 anyway, so storing it as bf16 loses nothing and halves two of the three streams
-template <bool ACC, bool BF = false>
+// SP (split rows, xsplit_dev.h): dst is written as [hi x4 | lo x4] bf16 groups at the addresses of the float32 values - the two consumers of dY (the
+// split-precision 1x1 dgrad / wgrad) then stage it verbatim instead of each converting and splitting every element again
+template <bool ACC, bool BF = false, bool SP = false>
 __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0,
                                                          const double* s1, double inv_count, const float* gamma, const float* mean,
                                                          const float* rstd, float* dgamma, float* dbeta, int M, int C4, int rows_per_block,
@@ -351,8 +355,10 @@ __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, co
     if constexpr (BF) {
       const bf16x2e lo = {(__bf16)__uint_as_float(r.x), (__bf16)__uint_as_float(r.y)}, hi = {(__bf16)__uint_as_float(r.z), (__bf16)__uint_as_float(r.w)};
       __builtin_amdgcn_raw_buffer_store_b64(u32x2e{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rd, voff, (int)soff, 0);
+    } else if constexpr (SP) {
+      buffer_store_b128_soffset(split_row4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)), rd, voff, (int)soff);
     } else {
-      __builtin_amdgcn_raw_buffer_store_b128(r, rd, voff, (int)soff, 0);
+      buffer_store_b128_soffset(r, rd, voff, (int)soff);            // (SGPR soffset: protected form, see rdm_common.h)
     }
   };
   auto one = [&](u32x4e z, u32x4e xv, u32x4e o) {
@@ -393,9 +399,9 @@ __global__ __launch_bounds__(256, 8) void k_bn_bwd_apply(float* dst, int ldd, co
 
 int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const float* x, int ldx, const double* s0, const double* s1, double count,
                         const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int M, int C, bool accumulate,
-                        int training, hipStream_t s, bool bf16_rows) {
+                        int training, hipStream_t s, bool bf16_rows, bool split_rows) {
   const int C4 = C / 4, gx = cdiv(C4, 64);
-  RDM_CHECK_ARG(!(bf16_rows && accumulate), "bn_bwd: bf16 rows are built for the plain (norm2) form");
+  RDM_CHECK_ARG(!((bf16_rows || split_rows) && accumulate) && !(bf16_rows && split_rows), "bn_bwd: bf16 / split rows are built for the plain (norm2) form, one at a time");
   const long ez = bf16_rows ? 2 : 4;
   const long eb[3] = {((long)(M - 1) * ldd + C) * ez, ((long)(M - 1) * ldz + C) * ez, ((long)(M - 1) * ldx + C) * 4};
   if (eb[0] >= 0xFFFFFFFFL || eb[1] >= 0xFFFFFFFFL || eb[2] >= 0xFFFFFFFFL) {
@@ -407,7 +413,38 @@ int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const flo
   dim3 grid(gx, cdiv(M, rpb));
   if (accumulate) hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
   else if (bf16_rows) hipLaunchKernelGGL((k_bn_bwd_apply<false, true>), grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
+  else if (split_rows) hipLaunchKernelGGL((k_bn_bwd_apply<false, false, true>), grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
   else hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, s, dst, ldd, dz, ldz, x, ldx, s0, s1, 1.0 / count, gamma, mean, rstd, dgamma, dbeta, M, C4, rpb, training, (unsigned)eb[0], (unsigned)eb[1], (unsigned)eb[2]);
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Activation -> SPLIT ROWS (xsplit_dev.h): dst[m][c] (row stride ldd floats' worth of bytes) = split(f(src[m][c])), f = ReLU(scale * x + shift) or the
+// identity.  The operand producer of the split-precision 1x1 weight gradient: relu1(norm1(x)) of a dense layer (RDM_Net.py:526-530 via
+// torchvision _DenseLayer) is formed and split ONCE per layer instead of once per 128-channel gradient tile inside the GEMM.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ src, int lds_, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    float* __restrict__ dst, int ldd, long M, int C4) {
+  const long total = M * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long m = idx / C4;
+    const int c = (int)(idx - m * C4) * 4;
+    f32x4e v = *reinterpret_cast<const f32x4e*>(src + m * lds_ + c);
+    if (scale) {
+      const f32x4e sc = *reinterpret_cast<const f32x4e*>(scale + c), sh = *reinterpret_cast<const f32x4e*>(shift + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+    }
+    *reinterpret_cast<xs_u32x4*>(dst + m * ldd + c) = split_row4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int launch_split_rows(const float* src, int ld_src, const float* scale, const float* shift, void* dst, int ld_dst, long M, int C, hipStream_t s) {
+  RDM_CHECK_ARG(C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "split_rows: channels / strides multiples of 4, operands 16-byte aligned");
+  RDM_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "split_rows: scale and shift go together, 16-byte aligned");
+  const long total = M * (C / 4);
+  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)std::min<long>(cdiv(total, 256), 256 * 16)), dim3(256), 0, s, src, ld_src, scale, shift, static_cast<float*>(dst), ld_dst, M, C / 4);
   RDM_LAUNCH_OK();
   return 0;
 }

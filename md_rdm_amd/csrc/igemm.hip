@@ -788,7 +788,7 @@ struct ProfScope {
   ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof.recs.push_back({a, b, flops, kind, bytes}); } }
 };
 // per-kernel breakdown of the last profile_read()
-constexpr int PROF_KINDS = 18;
+constexpr int PROF_KINDS = 19;
 const char* const kProfKindName[PROF_KINDS] = {
     "conv_fwd_kernel (forward / weights k-contiguous)", "conv_fwd_kernel (dgrad / weights k-strided)", "conv3x3_halo_kernel (forward)",
     "conv3x3_halo_kernel (dgrad)", "conv_wgrad_kernel (1x1)", "conv_wgrad_kernel (taps)", "(unused since round 4: the 3x3 row weight-gradient kernel was deleted)",
@@ -798,7 +798,8 @@ const char* const kProfKindName[PROF_KINDS] = {
     "gemm_panel_bf16_kernel (short-K 1x1 forward, persistent panels, bf16 MFMA)", "conv3x3_act_bf16_kernel (3x3 forward on an activated input, LDS-DMA, bf16 MFMA)",
     "xs_wgrad1x1_kernel (1x1 weight gradient, bf16x3 split MFMA; FLOPs = the f32 product's)", "xs_dgrad3x3_kernel (3x3 input gradient, bf16x3 split MFMA; FLOPs = the f32 product's)",
     "xs_wgrad3x3_kernel (3x3 weight gradient, bf16x3 split MFMA; FLOPs = the f32 product's)", "xs_dgrad1x1_kernel (1x1 input gradient, bf16x3 split MFMA; FLOPs = the f32 product's)",
-    "xs_fwd1x1_kernel (1x1 forward, bf16x6 three-way split MFMA; FLOPs = the f32 product's)"};
+    "xs_fwd1x1_kernel (1x1 forward, bf16x6 three-way split MFMA; FLOPs = the f32 product's)",
+    "conv3x3_wino_x6_kernel (Winograd F(2x2,3x3) forward, bf16x6 three-way split MFMA; FLOPs = the direct convolution's)"};
 double g_kind_ms[PROF_KINDS], g_kind_flops[PROF_KINDS], g_kind_bytes[PROF_KINDS];
 int g_kind_n[PROF_KINDS];
 }  // namespace

@@ -159,6 +159,9 @@ static hipStream_t shared_side_stream(bool default_priority) {
   return s;
 }
 
+// pixel counts from which layout() sizes the per-layer pack buffers of the split kernels; xs_block() / xf_block() can never select below them
+constexpr int XS_LAYOUT_MIN_PIXELS = 1024, XF_LAYOUT_MIN_PIXELS = 8192;
+
 struct NetImpl {
   int B, H0, W0, H1, W1;
   BlockGeom bg[4];
@@ -197,7 +200,9 @@ struct NetImpl {
   // Winograd F(2x2, 3x3) for the 3x3 convs of the blocks with many pixels (wino.hip): transformed weights per layer (formed on the side
   // stream at the start of forward) and one scratch for the per-split partial outputs
   bool wino_fwd[4] = {false, false, false, false}, wino_wg[4] = {false, false, false, false};
-  int wino_split[4] = {1, 1, 1, 1};
+  int wino_split[4] = {1, 1, 1, 1}, wino_split_x6[4] = {1, 1, 1, 1};
+  int opt_wino_x6 = 1;         // RDM_NET_OPT_WINO_X6: the Winograd forward of those blocks on the bf16x6 kernel (float32-equivalent, bf16 matrix pipe)
+  bool wino_x6(int b) const { return opt_wino_x6 && opt_split_fwd && !opt_det && wino_fwd[b]; }
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)
   size_t xsW = 0, xsWBytes = 0, xfW = 0, xfWBytes = 0;
@@ -221,13 +226,15 @@ struct NetImpl {
   // weight / input gradients and the 3x3 input gradient (173 -> 100, 134 -> 86, 63 -> 45 us per layer) but not on the 3x3 weight gradient (51 -> 56 us);
   // the decoder (1 280 pixels) lost overall while every layer paid two weight-pack launches and the norm1 pass on its chain (53.3 vs 52.6 ms per step);
   // with RDM_NET_OPT_PREPACK and RDM_NET_OPT_DEFER_NORM1 it gains (49.8-50.1 vs 50.4-50.7): the threshold is the kernels' own minimum
-  int xs_min_pixels = 1024;
+  int xs_min_pixels = XS_LAYOUT_MIN_PIXELS;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
+  int opt_split_rows = 1;      // RDM_NET_OPT_SPLIT_ROWS: dY and relu1(norm1(x)) reach the split 1x1 gradient kernels as SPLIT ROWS (xsplit_dev.h) written once by their producers
+  size_t xsXh = 0;             // split rows of the activation operand of the layer whose 1x1 weight gradient is running (side stream: one at a time)
   int opt_defer_norm1 = 1;     // RDM_NET_OPT_DEFER_NORM1: see k_bn_bwd_defer (elementwise.hip); blocks on the xs 1x1 dgrad only
   int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
   int xs_np() const { return (opt_gemm_bf16 & 2) ? 1 : 3; }      // value bits: 1 = the forward GEMMs, 2 = the gradient GEMMs (3 = both)
   int opt_split_fwd = 0;       // RDM_NET_OPT_SPLIT_FWD: conv1 of the many-pixel blocks on the three-way-split bf16x6 forward kernel
-  int xf_min_pixels = 8192;
+  int xf_min_pixels = XF_LAYOUT_MIN_PIXELS;
   bool xf_block(int b) const { return opt_split_fwd && !opt_det && bg[b].M >= xf_min_pixels; }
   int xs_wg3_min_pixels = 8192;
   bool xs_block_wgrad3(int b) const { return xs_block(b) && bg[b].M >= xs_wg3_min_pixels; }
@@ -344,9 +351,11 @@ struct NetImpl {
       if (!wino_fwd[b]) continue;
       const int T = B * ((bg[b].H + 1) / 2) * ((bg[b].W + 1) / 2);
       wino_split[b] = wino_pick_split(T, bg[b].cb / 16);
-      if (wino_split[b] > 1) winoPartialFloats = std::max(winoPartialFloats, (size_t)wino_split[b] * bg[b].M * 48);
+      wino_split_x6[b] = wino_pick_split(T, bg[b].cb / 16, true);
+      const int sp = std::max(wino_split[b], wino_split_x6[b]);              // options arrive after the layout: sized for either kernel
+      if (sp > 1) winoPartialFloats = std::max(winoPartialFloats, (size_t)sp * bg[b].M * 48);
       winoU[b].resize(kBlocks[b].layers);
-      for (auto& o : winoU[b]) o = a.take<float>((size_t)16 * 48 * bg[b].cb);
+      for (auto& o : winoU[b]) o = a.take<unsigned char>(std::max(wino_u_bytes(bg[b].cb, false), wino_u_bytes(bg[b].cb, true)));
     }
     winoPartial = a.take<float>(winoPartialFloats);
     for (int b = 0; b < 4; ++b)
@@ -358,25 +367,31 @@ struct NetImpl {
     winoQ = a.take<float>(winoQFloats);
     // split-precision backward (xsplit.hip): fragment-order split weights of the layer whose 3x3 input gradient is running (main stream)
     for (int b = 0; b < 4; ++b)
-      if (bg[b].M >= 1024) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
+      if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) xsWBytes = std::max({xsWBytes, xs_dgrad3x3_workspace_bytes(bg[b].cb), xs_dgrad1x1_workspace_bytes(bg[b].cb, bg[b].ctot)});
     xsW = a.take<unsigned char>(xsWBytes);
     for (int b = 0; b < 4; ++b) {
-      if (bg[b].M >= 1024) {
+      if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) {
         xsP3[b].resize(kBlocks[b].layers); xsP1[b].resize(kBlocks[b].layers);
         for (int i = 0; i < kBlocks[b].layers; ++i) {
           xsP3[b][i] = a.take<unsigned char>(xs_dgrad3x3_workspace_bytes(bg[b].cb));
           xsP1[b][i] = a.take<unsigned char>(xs_dgrad1x1_workspace_bytes(bg[b].cb, kBlocks[b].cin + i * GROWTH));
         }
       }
-      if (bg[b].M >= 8192) {
+      if (bg[b].M >= XF_LAYOUT_MIN_PIXELS) {
         xfP[b].resize(kBlocks[b].layers);
         for (int i = 0; i < kBlocks[b].layers; ++i) xfP[b][i] = a.take<unsigned char>(xs_fwd1x1_workspace_bytes(kBlocks[b].cin + i * GROWTH, bg[b].cb));
       }
     }
+    {
+      size_t xh = 0;                                             // [M][cin] split rows of the widest layer of every block on the split kernels
+      for (int b = 0; b < 4; ++b)
+        if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) xh = std::max(xh, (size_t)bg[b].M * (size_t)(kBlocks[b].cin + (kBlocks[b].layers - 1) * GROWTH));
+      xsXh = a.take<float>(xh);
+    }
     for (int b = 0; b < 4; ++b) deferLd = std::max(deferLd, (bg[b].ctot + 63) / 64 * 64);
     deferBC = a.take<float>((size_t)4 * deferLd);
     for (int b = 0; b < 4; ++b)
-      if (bg[b].M >= 1024) xfWBytes = std::max(xfWBytes, xs_fwd1x1_workspace_bytes(bg[b].ctot, bg[b].cb));
+      if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) xfWBytes = std::max(xfWBytes, xs_fwd1x1_workspace_bytes(bg[b].ctot, bg[b].cb));
     xfW = a.take<unsigned char>(xfWBytes);
     // backward scratch
     size_t maxMC = 0, maxMCin = 0, maxC = 0, maxP = 0, maxCb = 0;
@@ -565,7 +580,8 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
       WinoConv wv{};
       wv.A = Y; wv.lda = g.cb; wv.C = g.cb; wv.a_scale = bn2; wv.a_shift = bn2 + g.cb; wv.U = at<float>(ws, n.winoU[b][i]);
       wv.out = blk + cin; wv.ldc = g.ctot; wv.N = GROWTH; wv.B = n.B; wv.H = g.H; wv.W = g.W;
-      wv.split = n.wino_split[b]; wv.partial = at<float>(ws, n.winoPartial); wv.partial_floats = n.winoPartialFloats;
+      wv.x6 = n.wino_x6(b);
+      wv.split = wv.x6 ? n.wino_split_x6[b] : n.wino_split[b]; wv.partial = at<float>(ws, n.winoPartial); wv.partial_floats = n.winoPartialFloats;
       if (training) { wv.stat0 = bst + cin; wv.stat1 = bst + g.ctot + cin; }
       if ((rc = launch_conv3x3_wino_fwd(wv, s))) return rc;
     } else {
@@ -616,6 +632,19 @@ int forward_transition(NetImpl& n, int t, void* ws, void* const* T, int training
 int zero_f32(float* p, size_t n, hipStream_t s) {
   if (int rc = launch_zero_rows(p, 1, (long)n, (long)n, s)) return rc;
   return 0;
+}
+
+// every layer of block b can run the split 1x1 input gradient (whose epilogue carries the deferred norm1 backward)?
+static bool block_defers_norm1(const NetImpl& n, int b) {
+  if (!n.xs_block(b)) return false;
+  const BlockGeom& g = n.bg[b];
+  for (int i = 0; i < kBlocks[b].layers; ++i) {
+    FwdArgs e{};
+    e.g = geom1x1(n.B, g.H, g.W);
+    e.C = g.cb; e.N = kBlocks[b].cin + i * GROWTH; e.M = g.M;
+    if (!xs_dgrad1x1_supported(e)) return false;
+  }
+  return true;
 }
 
 int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, void* const* T, void* const* Gr, hipStream_t s) {
@@ -693,6 +722,18 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       dz_bf16 = n.xs_np() == 1 && n.xs_block(b) && xs_dgrad3x3_supported(d) && xs_dgrad1x1_supported(e1) && xs_wgrad1x1_supported(w1) && g.M >= 1024 && Gr[L.conv1] != nullptr;
     }
     d.out_bf16 = dz_bf16;
+    // float32 mode (three products): dY leaves the norm2 backward as SPLIT ROWS when both of its consumers are the split kernels - they stage it
+    // verbatim instead of each converting and splitting every element (RDM_NET_OPT_SPLIT_ROWS)
+    bool dy_split = false, xh_split = false;
+    {
+      FwdArgs e1{};
+      e1.g = geom1x1(n.B, g.H, g.W); e1.C = cb; e1.N = cin; e1.M = g.M;
+      WgradArgs w1{};
+      w1.g = geom1x1(n.B, g.H, g.W); w1.N = cb; w1.C = cin;
+      const bool wg_ok = xs_wgrad1x1_supported(w1);
+      dy_split = n.opt_split_rows && n.xs_np() == 3 && n.xs_block(b) && g.M >= 1024 && xs_dgrad1x1_supported(e1) && (Gr[L.conv1] == nullptr || wg_ok);
+      xh_split = n.opt_split_rows && n.xs_np() == 3 && n.xs_block(b) && g.M >= 1024 && Gr[L.conv1] != nullptr && wg_ok;
+    }
     if (n.xs_block(b) && xs_dgrad3x3_supported(d)) {
       const bool pk = n.pk_bwd_valid && !n.xsP3[b].empty();
       if ((rc = launch_xs_dgrad3x3(d, EPI_MASK_STATS, at<unsigned char>(ws, pk ? n.xsP3[b][i] : n.xsW), pk ? xs_dgrad3x3_workspace_bytes(cb) : n.xsWBytes, s, n.xs_np(), pk))) return rc;
@@ -700,7 +741,7 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     // one elementwise pass dZ := dY (BN-backward coefficients computed in the same kernel).  Forming dY inside the conv1
     // dgrad / wgrad loaders instead was measured slower (heavier loaders cost the MFMA kernels more: 155 vs 164 img/s)
     if ((rc = launch_bn_bwd_apply(dZ, cb, dZ, cb, Y, cb, s0, s1, (double)g.M, F(T, L.bn2.w), bn2 + 2 * cb, bn2 + 3 * cb,
-                                  Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s, dz_bf16)))
+                                  Gr[L.bn2.w] ? F(Gr, L.bn2.w) : nullptr, Gr[L.bn2.b] ? F(Gr, L.bn2.b) : nullptr, g.M, cb, false, training, s, dz_bf16, dy_split)))
       return rc;
     // ---- side stream: conv1 (1x1) wgrad straight into the PyTorch-layout gradient ([cb][cin][1][1]) ----
     if (Gr[L.conv1]) {
@@ -716,6 +757,13 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       w.dW = F(Gr, L.conv1); w.wtap = 0; w.ldw = cin;
       w.xsplit = n.xs_block(b) ? n.xs_np() : 0;
       w.g_bf16 = dz_bf16;
+      w.g_split = dy_split;
+      if (xh_split) {
+        // relu1(norm1(x)) of this layer, activated and split ONCE (the GEMM re-stages its activation tile for each of its cb / 128 gradient tiles)
+        float* xh = at<float>(ws, n.xsXh);
+        if ((rc = launch_split_rows(blk, g.ctot, bn1, bn1 + cin, xh, cin, g.M, cin, side))) return rc;
+        w.Xs = xh; w.ldx = cin; w.x_scale = nullptr; w.x_shift = nullptr; w.x_split = 1;
+      }
       if ((rc = launch_conv_wgrad(w, side))) return rc;
       RDM_HIP_OK(hipEventRecord(n.ev_dz[par], side));
       n.dz_busy[par] = true;
@@ -730,8 +778,10 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
     e.out = dZ1; e.ldc = cin; e.M = g.M; e.N = cin;
     e.stat0 = s0; e.stat1 = s1; e.X = blk; e.ldx = g.ctot; e.x_scale = bn1; e.x_shift = bn1 + cin;
     e.a_bf16 = dz_bf16;
+    e.a_split = dy_split;
     const bool xs_d1 = n.xs_block(b) && xs_dgrad1x1_supported(e);
-    const bool defer = xs_d1 && n.opt_defer_norm1;
+    // deferred norm1 backward: decided once per BLOCK - a layer that did not take it would neither consume nor forward the running (b, c) sums
+    const bool defer = xs_d1 && n.opt_defer_norm1 && block_defers_norm1(n, b);
     if (defer) { e.out = G; e.ldc = g.ctot; e.acc_scaled = 1; }          // the epilogue adds (gamma * rstd) * dz into the block gradient itself
     if (xs_d1) {
       const bool pk = n.pk_bwd_valid && !n.xsP1[b].empty();
@@ -845,11 +895,36 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_DIRECT_3X3) n->opt_no_wino = value != 0;
   else if (option == RDM_NET_OPT_DETERMINISTIC) n->opt_det = value != 0;
   else if (option == RDM_NET_OPT_JOIN_PER_SEGMENT) n->opt_join_seg = value != 0;
-  else if (option == RDM_NET_OPT_SPLIT_BWD) { n->opt_split_bwd = value != 0; if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = atoi(getenv("RDM_XS_MIN_PIXELS")); if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = atoi(getenv("RDM_XS_WG3_MIN")); }
-  else if (option == RDM_NET_OPT_PREPACK) n->opt_prepack = getenv("RDM_PREPACK") ? atoi(getenv("RDM_PREPACK")) != 0 : value != 0;
-  else if (option == RDM_NET_OPT_DEFER_NORM1) n->opt_defer_norm1 = getenv("RDM_DEFER_NORM1") ? atoi(getenv("RDM_DEFER_NORM1")) != 0 : value != 0;      // (the environment wins: A/B runs of bench.py)
+  // (environment overrides exist in DEVELOPMENT builds only - RDM_DEV_VARIANTS=1, in-process A/B runs of bench.py; the shipped library reads no
+  // environment: an option is what the caller set.  Thresholds are clamped to what layout() sized the pack buffers for.)
+  else if (option == RDM_NET_OPT_SPLIT_BWD) {
+    n->opt_split_bwd = value != 0;
+#ifdef RDM_DEV_VARIANTS
+    if (getenv("RDM_XS_MIN_PIXELS")) n->xs_min_pixels = std::max(XS_LAYOUT_MIN_PIXELS, atoi(getenv("RDM_XS_MIN_PIXELS")));
+    if (getenv("RDM_XS_WG3_MIN")) n->xs_wg3_min_pixels = std::max(XS_LAYOUT_MIN_PIXELS, atoi(getenv("RDM_XS_WG3_MIN")));
+#endif
+  }
+  else if (option == RDM_NET_OPT_PREPACK) {
+    n->opt_prepack = value != 0;
+#ifdef RDM_DEV_VARIANTS
+    if (getenv("RDM_PREPACK")) n->opt_prepack = atoi(getenv("RDM_PREPACK")) != 0;
+#endif
+  }
+  else if (option == RDM_NET_OPT_DEFER_NORM1) {
+    n->opt_defer_norm1 = value != 0;
+#ifdef RDM_DEV_VARIANTS
+    if (getenv("RDM_DEFER_NORM1")) n->opt_defer_norm1 = atoi(getenv("RDM_DEFER_NORM1")) != 0;
+#endif
+  }
   else if (option == RDM_NET_OPT_GEMM_BF16) n->opt_gemm_bf16 = value == 1 ? 3 : value == 2 ? 1 : value == 3 ? 2 : 0;      // 1 = both, 2 = forward GEMMs only, 3 = gradient GEMMs only
-  else if (option == RDM_NET_OPT_SPLIT_FWD) { n->opt_split_fwd = value != 0; if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = atoi(getenv("RDM_XF_MIN_PIXELS")); }
+  else if (option == RDM_NET_OPT_SPLIT_ROWS) n->opt_split_rows = value != 0;
+  else if (option == RDM_NET_OPT_WINO_X6) n->opt_wino_x6 = value != 0;
+  else if (option == RDM_NET_OPT_SPLIT_FWD) {
+    n->opt_split_fwd = value != 0;
+#ifdef RDM_DEV_VARIANTS
+    if (getenv("RDM_XF_MIN_PIXELS")) n->xf_min_pixels = std::max(XF_LAYOUT_MIN_PIXELS, atoi(getenv("RDM_XF_MIN_PIXELS")));
+#endif
+  }
   else { set_error("rdm_net_set_option: unknown option %d", option); return RDM_ERR_BAD_ARGUMENT; }
   return RDM_OK;
 }
@@ -949,7 +1024,7 @@ int rdm_net_forward(rdm_net* net, const float* x, void* const* T, void* ws, size
     if (n.wino_fwd[b] && !n.opt_no_wino)
       for (int i = 0; i < kBlocks[b].layers; ++i) {
         const float* w2p = n.opt_packed3x3 ? F(T, reg().layers[b][i].conv2) : at<float>(ws, n.lws[b][i].w2p);
-        if ((rc = launch_wino_weight(w2p, (long)GROWTH * n.bg[b].cb, n.bg[b].cb, GROWTH, n.bg[b].cb, at<float>(ws, n.winoU[b][i]), n.side))) return rc;
+        if ((rc = launch_wino_weight(w2p, (long)GROWTH * n.bg[b].cb, n.bg[b].cb, GROWTH, n.bg[b].cb, at<float>(ws, n.winoU[b][i]), n.side, n.wino_x6(b)))) return rc;
       }
   RDM_HIP_OK(hipEventRecord(n.ev_side, n.side));
   // ... and, behind everything the forward waits for, the split / fragment-order images the BACKWARD's input-gradient kernels read (the weights

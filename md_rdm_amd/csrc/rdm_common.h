@@ -103,6 +103,7 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   // mixed-precision arithmetic mode, xsplit.hip kernels with one bf16 MFMA per product only: `out` (3x3 dgrad) / `A` (1x1 dgrad) are rows of bf16
   // (ldc / lda in elements of that type)
   int out_bf16, a_bf16;
+  int a_split;                                // xs 1x1 dgrad, three-product form: A (the gradient operand) is SPLIT ROWS (xsplit_dev.h)
   // xs 1x1 dgrad with the gate epilogue only: `out` is the block gradient and receives  out += x_scale * (gated dz)  (deferred norm1 backward)
   int acc_scaled;
 };
@@ -135,6 +136,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
   int xsplit;                                 // != 0: the kernels of xsplit.hip may serve this launch (gradients only): 3 (or any value but 1) = split precision,
                                               // three bf16 MFMAs per product; 1 = operands rounded to bf16, one MFMA (the mixed-precision mode)
   int g_bf16;                                 // xsplit == 1 only: G is rows of bf16 (ldg in elements of that type)
+  int g_split, x_split;                       // xsplit == 3, 1x1 only: G / Xs are SPLIT ROWS (xsplit_dev.h; Xs then already activated: no x_scale / x_shift)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);
@@ -149,5 +151,21 @@ int profile_kind(int kind, const char** name, double* ms_sum, double* flops, int
 size_t nyu_preprocess_workspace_bytes(int B, int H, int W, int h1, int w1, int out_w);
 int launch_nyu_preprocess(const unsigned char* rgb, const float* depth, const void* aug_dev, int B, int H, int W, int h1, int w1, int oh, int ow,
                           float* x, float* y, void* ws, size_t ws_bytes, hipStream_t s);
+
+
+// ---- 128-bit buffer stores with a SCALAR offset: MI355X needs a wait state the compiler does not insert --------------------------------
+// A MUBUF store of more than 64 bits must not have its data VGPRs overwritten in the next 1-2 issue slots.  hipcc (LLVM
+// GCNHazardRecognizer::createsVALUHazard) inserts those wait states EXCEPT when the store's soffset is an SGPR - the ISA manual's exemption.
+// On gfx950 the exemption does not hold: tools/store_hazard/store_hazard_probe.hip (profiles/r05_store_hazard_probe.txt) stores the
+// OVERWRITTEN dword 0 in lanes 12-15 of every 16 when a VALU write follows the store directly, and stores correctly behind one s_nop.  (Found in
+// round 4 as "wrong values in lanes 12-15" of xs_dgrad3x3_kernel's gated output.)  Every >64-bit buffer store with a runtime scalar offset goes
+// through this helper: the store and its two wait states are one asm block, so no schedule can separate them.
+// tools/store_hazard/scan_isa.py audits the compiled ISA of the whole library for the unprotected pattern (tests/test_boundary.py runs it).
+typedef unsigned int rdm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store_b128_soffset(rdm_u32x4 data, __amdgpu_buffer_rsrc_t srd, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(data), "v"(voffset), "s"(srd), "s"(soffset) : "memory");
+#endif
+}
 
 }  // namespace rdm

@@ -12,6 +12,7 @@ struct WinoConv {
   int split;                                      // 0: launcher's choice; > 1 needs `partial`
   float* partial; size_t partial_floats;          // scratch for the per-split partial outputs, split * B*H*W * 48 floats
   double* stat0; double* stat1;                   // optional: += sum / sum of squares of the output per channel
+  int x6;                                         // 1: the bf16x6 kernel (float32-equivalent, bf16 matrix pipe); U then in launch_wino_weight(..., x6 = true) form
 };
 struct WinoWgrad {                                // dW[tap][n][c] = sum_m G[m][n] * f(A[pix(m, tap)][c]), written (not accumulated)
   const float* G; int ldg; int N;                 // output gradient, N <= 48 channels
@@ -25,8 +26,9 @@ struct WinoWgrad {                                // dW[tap][n][c] = sum_m G[m][
 size_t wino_wgrad_vy_floats(int B, int H, int W);
 size_t wino_wgrad_part_floats(int B, int H, int W, int C);
 int launch_conv3x3_wino_wgrad(const WinoWgrad& a, hipStream_t s);
-size_t wino_fwd_workspace_bytes(int C, long M, int split);
-int wino_pick_split(int tiles, int nslab);
-int launch_wino_weight(const float* w_packed, long wtap, int ldw, int N, int C, float* U, hipStream_t s);
+size_t wino_u_bytes(int C, bool x6);                                       // transformed-weight image of one layer
+size_t wino_fwd_workspace_bytes(int C, long M, int split, bool x6 = false);
+int wino_pick_split(int tiles, int nslab, bool x6 = false);
+int launch_wino_weight(const float* w_packed, long wtap, int ldw, int N, int C, float* U, hipStream_t s, bool x6 = false);
 int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s);
 }  // namespace rdm

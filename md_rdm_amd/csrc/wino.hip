@@ -350,6 +350,304 @@ __global__ __launch_bounds__(256) void k_wino_reduce(const float* __restrict__ p
 
 
 // =============================================================================================
+// The same forward on the bf16 matrix pipe, float32-EQUIVALENT ("bf16x6", round 5): the 16 position GEMMs of F(2x2, 3x3) with both operands split
+// three ways AFTER their transforms,  v = v0 + v1 + v2  (bf16 each, 24 significant bits together), u likewise, and
+//     v u ~ v0 u0 + v1 u0 + v0 u1 + v2 u0 + v0 u2 + v1 u1            (dropped terms 2^-24 relative; every bf16 x bf16 product exact in float32)
+// - the arithmetic of xs_fwd1x1_kernel (xsplit.hip), 6 x 1 / 2.25 = 2.7x the direct convolution's products on a pipe that is 16x faster than the
+// f32 MFMA's.  Replaces conv3x3_wino_fwd_kernel for conv2 of dense_e2 / dense_e3 (torchvision _DenseLayer.conv2, network/RDM_Net.py:526,528).
+//  * K packing: a slab is 16 channels, a v_mfma_f32_16x16x32_bf16 contracts 32 k-slots - two PLANES of the slab side by side.  Three MFMAs
+//    per (position, 16-tile block, 16-output block):   (v0|v1).(u0|u0)   (v0|v2).(u1|u0)   (v0|v1).(u2|u1)   = the six products.
+//  * V image in LDS: one 96-byte row per (position, tile) = [v0: 16 ch | v1 | v2]; fragment (v0|v1) = bytes 16 g .. 16 g + 15 of the row for
+//    k-group g, (v0|v2) the same with +32 for g >= 2.  Row stride 96 B = 6 sixteen-byte slots: the gfx950 ds_read_b128 lane groups
+//    (MI355X_MICROARCH.md, LDS) then hit 16 distinct slots (6 l16 + g mod 16: even slots for even g, odd for odd) - conflict-free without a
+//    swizzle - and so do the producers' 8-byte stores (12 tl + cq mod 32).
+//  * 48 tiles per workgroup (3 consumer M-tiles: 144 accumulator registers - 64 tiles would need 192 + 72 of weight fragments), so the image
+//    (72 KB) is DOUBLE-buffered like the f32 kernel's; 3 producer waves (192 threads = 48 tiles x 4 channel quads) + 4 consumer waves.
+//  * U: k_wino_weight_x6 writes, per (slab, position, 16-output block), the three planes as 512-byte blocks [k-half][n][8 ch]; the three B
+//    fragments are addressed into them per lane ((u0|u0) reads one block twice, the second lane pair hits the same cache lines).
+// =============================================================================================
+constexpr int TX = 48;                                    // tiles per workgroup
+constexpr int XROW = 96;                                  // bytes per (position, tile) row of the V image
+constexpr int XIMG = 16 * TX * XROW;                      // one buffer: 73 728 B
+constexpr int XU_BLOCK = 512, XU_PNT = 3 * XU_BLOCK;      // bytes per plane block / per (slab, position, nt)
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+
+// x -> three bf16 planes for four values (round to nearest even at every step: x0 + x1 + x2 = x to 24 bits)
+__device__ __forceinline__ void wsplit3x4(const float a, const float b, const float c, const float d, u32x2& p0, u32x2& p1, u32x2& p2) {
+  const bf16x2w a01 = {(__bf16)a, (__bf16)b}, a23 = {(__bf16)c, (__bf16)d};
+  const float r0 = a - (float)a01[0], r1 = b - (float)a01[1], r2 = c - (float)a23[0], r3 = d - (float)a23[1];
+  const bf16x2w b01 = {(__bf16)r0, (__bf16)r1}, b23 = {(__bf16)r2, (__bf16)r3};
+  const float q0 = r0 - (float)b01[0], q1 = r1 - (float)b01[1], q2 = r2 - (float)b23[0], q3 = r3 - (float)b23[1];
+  const bf16x2w c01 = {(__bf16)q0, (__bf16)q1}, c23 = {(__bf16)q2, (__bf16)q3};
+  p0 = u32x2{__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23)};
+  p1 = u32x2{__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23)};
+  p2 = u32x2{__builtin_bit_cast(unsigned, c01), __builtin_bit_cast(unsigned, c23)};
+}
+
+// U = G g G^T, split three ways, block order [slab][pos][nt][plane][k-half h][n = nt*16 + l16][8 ch: c = slab*16 + 8 h + e]
+__global__ __launch_bounds__(256) void k_wino_weight_x6(const float* __restrict__ w, long wtap, int ldw, int N, int C, unsigned char* __restrict__ U) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per (slab, nt, l16, h, quad): 4 channels x 16 positions
+  const int quad = (int)(idx & 1), h = (int)((idx >> 1) & 1), l16 = (int)((idx >> 2) & 15);
+  const long r1 = idx >> 6;
+  const int nt = (int)(r1 % 3), slab = (int)(r1 / 3);
+  if (slab >= C / 16) return;
+  const int n = nt * 16 + l16;
+  float u[16][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = slab * 16 + 8 * h + 4 * quad + e;
+    float gg[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) gg[r][q] = n < N ? w[(long)(r * 3 + q) * wtap + (long)n * ldw + c] : 0.f;
+    float t[4][3];                                               // G g
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      t[0][q] = gg[0][q];
+      t[1][q] = 0.5f * (gg[0][q] + gg[1][q] + gg[2][q]);
+      t[2][q] = 0.5f * (gg[0][q] - gg[1][q] + gg[2][q]);
+      t[3][q] = gg[2][q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i * 4 + 0][e] = t[i][0];
+      u[i * 4 + 1][e] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      u[i * 4 + 2][e] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      u[i * 4 + 3][e] = t[i][2];
+    }
+  }
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos) {
+    u32x2 p0, p1, p2;
+    wsplit3x4(u[pos][0], u[pos][1], u[pos][2], u[pos][3], p0, p1, p2);
+    unsigned char* dst = U + (((long)slab * 16 + pos) * 3 + nt) * XU_PNT + h * 256 + l16 * 16 + quad * 8;
+    *reinterpret_cast<u32x2*>(dst) = p0;
+    *reinterpret_cast<u32x2*>(dst + XU_BLOCK) = p1;
+    *reinterpret_cast<u32x2*>(dst + 2 * XU_BLOCK) = p2;
+  }
+}
+
+struct WinoX6Args {
+  const float* A; int lda; int C;
+  const float* a_scale; const float* a_shift;
+  const unsigned char* U;
+  float* out; int ldc; int N;
+  int B, H, W, TH, TW, T;
+  int split;
+  unsigned a_bytes, u_bytes;
+};
+
+template <bool BNRELU>
+__global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wx_smem[];      // V double buffer: 2 x XIMG; reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int nslab = p.C / 16;
+  int s_begin = 0, s_end = nslab;
+  if (p.split > 1) {
+    const int per = (nslab + p.split - 1) / p.split;
+    s_begin = blockIdx.y * per;
+    s_end = min(nslab, s_begin + per);
+  }
+  const int tile0 = blockIdx.x * TX;
+  const bool producer = wave >= 4;
+  const int pos0 = (wave & 3) * 4;
+  f32x4 acc[4][3][3];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc[pp][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    if (producer) {
+      // ---- producer: thread -> channel quad cq of tile tl; gather, BatchNorm + ReLU + padding mask, the two 1-D transforms (all as in the f32
+      // kernel), then the three-way split and three 8-byte LDS stores per position ----
+      const int ptid = tid - 256, tl = ptid >> 2, cq = ptid & 3;
+      unsigned voff[16];
+      float hi[16];
+      {
+        const int t = tile0 + tl;
+        const bool tok = t < p.T;
+        const int tpi = p.TH * p.TW;
+        const int b = t / tpi, rem = t - b * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+            const bool ok = tok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            voff[i * 4 + j] = ok ? (unsigned)((b * p.H + y) * p.W + x) * (unsigned)(p.lda * 4) + (unsigned)(cq * 16) : WOOB;
+            hi[i * 4 + j] = ok ? __builtin_inff() : 0.f;
+          }
+      }
+      const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
+      const unsigned rowoff = (unsigned)(tl * XROW + cq * 8);
+      float rv[4][16];
+      auto load_raw = [&](int s) {
+        const int so = s * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srdA, (int)voff[q], so, 0);
+          rv[0][q] = __uint_as_float(v.x); rv[1][q] = __uint_as_float(v.y); rv[2][q] = __uint_as_float(v.z); rv[3][q] = __uint_as_float(v.w);
+        }
+      };
+      auto transform_store = [&](int s, unsigned char* Vb) {
+        if (BNRELU) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.a_scale + s * 16 + cq * 4), sh = *reinterpret_cast<const f32x4*>(p.a_shift + s * 16 + cq * 4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rv[c][q] = __builtin_amdgcn_fmed3f(fmaf(rv[c][q], sc[c], sh[c]), 0.f, hi[q]);
+        }
+#define RDM_WINO_1D(v, i0, i1, i2, i3)                                                        \
+        { const float d0 = v[i0], d1 = v[i1], d2 = v[i2], d3 = v[i3];                         \
+          v[i0] = d0 - d2; v[i1] = d1 + d2; v[i2] = d2 - d1; v[i3] = d1 - d3; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) RDM_WINO_1D(rv[c], j, 4 + j, 8 + j, 12 + j)                      // B^T d: columns
+#pragma unroll
+          for (int i = 0; i < 4; ++i) RDM_WINO_1D(rv[c], 4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3)      // (.) B: rows
+        }
+#undef RDM_WINO_1D
+        if (tl < TX) {
+#pragma unroll
+          for (int pos = 0; pos < 16; ++pos) {
+            u32x2 p0, p1, p2;
+            wsplit3x4(rv[0][pos], rv[1][pos], rv[2][pos], rv[3][pos], p0, p1, p2);
+            unsigned char* row = Vb + pos * (TX * XROW) + rowoff;
+            *reinterpret_cast<u32x2*>(row) = p0;
+            *reinterpret_cast<u32x2*>(row + 32) = p1;
+            *reinterpret_cast<u32x2*>(row + 64) = p2;
+          }
+        }
+      };
+      load_raw(s_begin);
+      transform_store(s_begin, wx_smem);
+      load_raw(min(s_begin + 1, s_end - 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) {
+          transform_store(s + 1, wx_smem + (buf ^ 1) * XIMG);              // raw(s+1) has been in flight for a whole slab time
+          load_raw(min(s + 2, s_end - 1));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the LDS stores have landed before the barrier releases the readers
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // ---- consumer: positions pos0 .. pos0 + 3; per position 9 B fragments (3 output blocks x 3 MFMAs), per 16-tile block 2 A fragments ----
+      const __amdgpu_buffer_rsrc_t srdU = wsrd(p.U, p.u_bytes);
+      const unsigned h = (unsigned)(g & 1), hi2 = (unsigned)(g >> 1);
+      const unsigned ub1 = h * 256u + (unsigned)l16 * 16u;                                         // (u0|u0): block 0 for every k-group
+      const unsigned ub2 = (hi2 ? 0u : (unsigned)XU_BLOCK) + h * 256u + (unsigned)l16 * 16u;       // (u1|u0)
+      const unsigned ub3 = (hi2 ? (unsigned)XU_BLOCK : 2u * XU_BLOCK) + h * 256u + (unsigned)l16 * 16u;   // (u2|u1)
+      bf16x8w bq[2][3][3];
+      auto load_b = [&](int s, int pos, bf16x8w (&b)[3][3]) {
+        const int so = ((s * 16 + pos) * 3) * XU_PNT;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          b[nt][0] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub1, so + nt * XU_PNT, 0));
+          b[nt][1] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub2, so + nt * XU_PNT, 0));
+          b[nt][2] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub3, so + nt * XU_PNT, 0));
+        }
+      };
+      const unsigned a1off = (unsigned)(l16 * XROW + g * 16), a2off = a1off + (hi2 ? 32u : 0u);
+      bf16x8w aq[2][2];
+      auto load_a = [&](const unsigned char* Vb, int pos, int mt, bf16x8w (&a)[2]) {
+        const unsigned char* r = Vb + (pos * TX + mt * 16) * XROW;
+        a[0] = *reinterpret_cast<const bf16x8w*>(r + a1off);
+        a[1] = *reinterpret_cast<const bf16x8w*>(r + a2off);
+      };
+      load_b(s_begin, pos0, bq[0]);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int s = s_begin; s < s_end; ++s) {
+        const unsigned char* Vb = wx_smem + ((s - s_begin) & 1) * XIMG;
+        load_a(Vb, pos0, 0, aq[0]);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp < 3) load_b(s, pos0 + pp + 1, bq[(pp + 1) & 1]);
+          else load_b(min(s + 1, s_end - 1), pos0, bq[0]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            const int cur = (pp * 3 + mt) & 1;
+            if (mt < 2) load_a(Vb, pos0 + pp, mt + 1, aq[cur ^ 1]);
+            else if (pp < 3) load_a(Vb, pos0 + pp + 1, 0, aq[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {                       // smallest terms first: (v0 u2 + v1 u1), (v0 u1 + v2 u0), (v0 u0 + v1 u0)
+              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[pp & 1][nt][2], acc[pp][mt][nt], 0, 0, 0);
+              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][1], bq[pp & 1][nt][1], acc[pp][mt][nt], 0, 0, 0);
+              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[pp & 1][nt][0], acc[pp][mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: M (16 positions, held by the consumers) -> LDS, one 16-tile block at a time; Y = A^T M A; store ----
+  float* Ms = reinterpret_cast<float*>(wx_smem);
+  const long Mtot = (long)p.B * p.H * p.W;
+  float* dst = p.split > 1 ? p.out + (long)blockIdx.y * Mtot * 48 : p.out;
+  const int ldo = p.split > 1 ? 48 : p.ldc;
+  const int tpi = p.TH * p.TW;
+#pragma unroll 1
+  for (int hblk = 0; hblk < 3; ++hblk) {
+    if (!producer) {
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Ms[((pos0 + pp) * 16 + 4 * g + r) * LDM + nt * 16 + l16] = hblk == 0 ? acc[pp][0][nt][r] : hblk == 1 ? acc[pp][1][nt][r] : acc[pp][2][nt][r];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 448;
+      const int tl2 = idx / 48, n = idx - tl2 * 48;
+      const int t = tile0 + hblk * 16 + tl2;
+      if (tl2 < 16 && t < p.T && n < p.N) {
+        float m[16];
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) m[pos] = Ms[(pos * 16 + tl2) * LDM + n];
+        float u[2][4];                                              // A^T M: rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { u[0][j] = m[j] + m[4 + j] + m[8 + j]; u[1][j] = m[4 + j] - m[8 + j] - m[12 + j]; }
+        const int b = t / tpi, rem = t - b * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const float y0 = u[a2][0] + u[a2][1] + u[a2][2], y1 = u[a2][1] - u[a2][2] - u[a2][3];
+          const int y = 2 * ty + a2, x = 2 * tx;
+          if (y < p.H) {
+            float* o = dst + ((long)(b * p.H + y) * p.W + x) * ldo + n;
+            o[0] = y0;
+            if (x + 1 < p.W) o[ldo] = y1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================
 // wgrad:  dW[r*3+q][n][c] = sum_m dOut[m][n] * f(Y[m + (r-1) W + (q-1)][c])     (K = all pixels, 48 x Cb outputs per tap)
 // Winograd F(3x3, 2x2): per 2x2 output tile the 3x3 filter gradient is  A3^T [ (G2 dy G2^T) (.) (B^T d B) ] A3  (16 multiplies instead
 // of 36), and the sum over tiles commutes with the output transform:  Q[pos][n][c] = sum_tiles Vy[pos][tile][n] * Vd[pos][tile][c]  are 16
@@ -617,16 +915,19 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restri
 
 }  // namespace
 
-size_t wino_fwd_workspace_bytes(int C, long M, int split) {
-  const size_t u = (size_t)16 * 48 * C * sizeof(float);
+size_t wino_u_bytes(int C, bool x6) { return x6 ? (size_t)(C / 16) * 16 * 3 * XU_PNT : (size_t)16 * 48 * C * sizeof(float); }
+
+size_t wino_fwd_workspace_bytes(int C, long M, int split, bool x6) {
+  const size_t u = wino_u_bytes(C, x6);
   const size_t part = split > 1 ? (size_t)split * M * 48 * sizeof(float) : 0;
   return ((u + 255) & ~(size_t)255) + ((part + 255) & ~(size_t)255);
 }
 
-int wino_pick_split(int T, int nslab) {
-  // one workgroup per CU (128 KB of LDS): the grid runs in ceil(blocks / 256) rounds.  Every split pays ~1.2 slab-times of prologue and
-  // epilogue; pick the split with the smallest (rounds x (slabs per split + 1.2)).
-  const long tb = (T + TT - 1) / TT;
+int wino_pick_split(int T, int nslab, bool x6) {
+  // one workgroup per CU (128 KB of LDS; 144 KB for the bf16x6 kernel): the grid runs in ceil(blocks / 256) rounds.  Every split pays ~1.2
+  // slab-times of prologue and epilogue; pick the split with the smallest (rounds x (slabs per split + 1.2)).
+  const int tt = x6 ? TX : TT;
+  const long tb = (T + tt - 1) / tt;
   int best = 1;
   double best_cost = 1e30;
   for (int sp = 1; sp <= 32 && sp <= nslab / 4 + 1; ++sp) {
@@ -637,11 +938,33 @@ int wino_pick_split(int T, int nslab) {
   return best;
 }
 
-int launch_wino_weight(const float* w, long wtap, int ldw, int N, int C, float* U, hipStream_t s) {
+int launch_wino_weight(const float* w, long wtap, int ldw, int N, int C, float* U, hipStream_t s, bool x6) {
   RDM_CHECK_ARG(C % 16 == 0 && N >= 1 && N <= 48, "winograd weights: C (%d) must be a multiple of 16 and N (%d) <= 48", C, N);
   const long threads = (long)(C / 16) * 3 * 64;
+  if (x6) {
+    hipLaunchKernelGGL(k_wino_weight_x6, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, wtap, ldw, N, C, reinterpret_cast<unsigned char*>(U));
+    RDM_LAUNCH_OK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_wino_weight, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, s, w, wtap, ldw, N, C, U);
   RDM_LAUNCH_OK();
+  return 0;
+}
+
+// tail of both forward kernels: split > 1: ordered sum of the partials into the output slice (+ statistics); split == 1 with statistics: one
+// pass over the slice.  Deterministic mode: the statistics come from the ordered column pass instead of the reduction's per-workgroup f64 atomics.
+static int wino_fwd_finish(const WinoConv& a, int split, long M, hipStream_t s) {
+  if (split > 1 || a.stat0) {
+    const bool stats_apart = a.stat0 && (split == 1 || t_deterministic);
+    if (split > 1) {
+      const int rpb = 84;                                     // 21 row lanes x 4 rows
+      hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, s, a.partial, split, M, a.N, a.out, a.ldc, stats_apart ? nullptr : a.stat0,
+                         stats_apart ? nullptr : a.stat1, rpb);
+      RDM_LAUNCH_OK();
+    }
+    if (stats_apart)
+      if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
+  }
   return 0;
 }
 
@@ -654,9 +977,28 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
   if (ab >= 0xFFFFFFFFL) { set_error("winograd 3x3: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
   const int TH = (a.H + 1) / 2, TW = (a.W + 1) / 2;
   const int T = a.B * TH * TW, nslab = a.C / 16;
-  int split = a.split > 0 ? std::min(a.split, nslab) : wino_pick_split(T, nslab);
+  int split = a.split > 0 ? std::min(a.split, nslab) : wino_pick_split(T, nslab, a.x6 != 0);
   if (split > 1 && a.partial == nullptr) split = 1;
   if (split > 1 && a.partial_floats < (size_t)split * M * 48) split = std::max<long>(1, (long)(a.partial_floats / ((size_t)M * 48)));
+  if (a.x6) {
+    WinoX6Args k{};
+    k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.U = reinterpret_cast<const unsigned char*>(a.U);
+    k.out = split > 1 ? a.partial : a.out; k.ldc = a.ldc; k.N = a.N;
+    k.B = a.B; k.H = a.H; k.W = a.W; k.TH = TH; k.TW = TW; k.T = T; k.split = split; k.a_bytes = (unsigned)ab; k.u_bytes = (unsigned)wino_u_bytes(a.C, true);
+    void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 18);
+    RDM_CENSUS("conv3x3_wino_x6_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", split > 1 ? "PARTIAL" : (a.stat0 ? "STORE+stats" : "STORE"));
+    dim3 grid((unsigned)cdiv(T, TX), (unsigned)split);
+    if (a.a_scale) {
+      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XIMG));
+      hipLaunchKernelGGL((conv3x3_wino_x6_kernel<true>), grid, dim3(448), 2 * XIMG, s, k);
+    } else {
+      RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XIMG));
+      hipLaunchKernelGGL((conv3x3_wino_x6_kernel<false>), grid, dim3(448), 2 * XIMG, s, k);
+    }
+    profile_end(prof, s);
+    RDM_LAUNCH_OK();
+    return wino_fwd_finish(a, split, M, s);
+  }
   WinoFwdArgs k{};
   k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.U = a.U;
   k.out = split > 1 ? a.partial : a.out; k.ldc = a.ldc; k.N = a.N;
@@ -675,20 +1017,7 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
   else hipLaunchKernelGGL((conv3x3_wino_fwd_kernel<false>), grid, dim3(512), 0, s, k);
   profile_end(prof, s);
   RDM_LAUNCH_OK();
-  if (split > 1 || a.stat0) {
-    // split > 1: ordered sum of the partials into the output slice (+ statistics); split == 1 with statistics: one pass over the slice.
-    // Deterministic mode: the statistics come from the ordered column pass instead of the reduction's per-workgroup f64 atomics.
-    const bool stats_apart = a.stat0 && (split == 1 || t_deterministic);
-    if (split > 1) {
-      const int rpb = 84;                                     // 21 row lanes x 4 rows
-      hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, s, a.partial, split, M, a.N, a.out, a.ldc, stats_apart ? nullptr : a.stat0,
-                         stats_apart ? nullptr : a.stat1, rpb);
-      RDM_LAUNCH_OK();
-    }
-    if (stats_apart)
-      if (int rc = launch_colstats(a.out, a.ldc, (int)M, a.N, a.stat0, a.stat1, s)) return rc;
-  }
-  return 0;
+  return wino_fwd_finish(a, split, M, s);
 }
 
 int wino_wgrad_split(int nslab, int cblocks) {

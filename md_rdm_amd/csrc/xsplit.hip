@@ -27,6 +27,7 @@
 #include "rdm_common.h"
 #include "elementwise.h"
 #include "xsplit.h"
+#include "xsplit_dev.h"
 
 namespace rdm {
 
@@ -44,15 +45,6 @@ constexpr unsigned XOOB = 0xFFFFFFFFu;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xsrd(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-
-// x -> (hi, lo) for four values: two packed bf16 pairs each (v_cvt_pk_bf16_f32: round to nearest even)
-__device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, u32x2& hi, u32x2& lo) {
-  const bf16x2 h01 = {(__bf16)v0, (__bf16)v1}, h23 = {(__bf16)v2, (__bf16)v3};
-  const float r0 = v0 - (float)h01[0], r1 = v1 - (float)h01[1], r2 = v2 - (float)h23[0], r3 = v3 - (float)h23[1];
-  const bf16x2 l01 = {(__bf16)r0, (__bf16)r1}, l23 = {(__bf16)r2, (__bf16)r3};
-  hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-  lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
 
 // one MFMA operand fragment (8 consecutive k of one row / column) from a [pixel][channel] image: two transposed 8-byte reads
@@ -75,6 +67,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsi
 struct XsWgradArgs {
   const float* G; int ldg; int N;
   int g_bf16;                   // NP == 1 only: G is rows of bf16 (ldg in elements)
+  int g_split, x_split;         // NP == 3 only: the operand is given as SPLIT ROWS (xsplit_dev.h: [hi x4 | lo x4] per four values, same addresses): staged verbatim
   const float* X; int ldx; int C;
   const float* x_scale; const float* x_shift;
   float* dW; int ldw;
@@ -165,6 +158,7 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
     for (int it = 0; it < 4; ++it) {
       u32x2 hi, lo;
       if (NP == 1 && p.g_bf16) hi = u32x2{__float_as_uint(ra[it][0]), __float_as_uint(ra[it][1])};
+      else if (NP == 3 && p.g_split) { hi = u32x2{__float_as_uint(ra[it][0]), __float_as_uint(ra[it][1])}; lo = u32x2{__float_as_uint(ra[it][2]), __float_as_uint(ra[it][3])}; }
       else split4(ra[it][0], ra[it][1], ra[it][2], ra[it][3], hi, lo);
       *reinterpret_cast<u32x2*>(Ahi + a_lds[it]) = hi;
       if (NP == 3) *reinterpret_cast<u32x2*>(Alo + a_lds[it]) = lo;
@@ -173,13 +167,17 @@ __device__ __forceinline__ void xs_wgrad1x1_body(const XsWgradArgs& p, unsigned 
     for (int it = 0; it < BL; ++it) {
       if (BPATCH % 16 != 0 && it == BL - 1 && grp + 16 * it >= BPATCH) continue;
       f32x4 v = rb[it];
-      if (bnrelu) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(Ssc + b_col[it]), sh = *reinterpret_cast<const f32x4*>(Ssc + BN + b_col[it]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], sc[e], sh[e]), 0.f, bhi[it]);
-      }
       u32x2 hi, lo;
-      split4(v[0], v[1], v[2], v[3], hi, lo);
+      if (NP == 3 && p.x_split) {                               // already activated and split by the producer (rows past M were loaded as zeros)
+        hi = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; lo = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])};
+      } else {
+        if (bnrelu) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(Ssc + b_col[it]), sh = *reinterpret_cast<const f32x4*>(Ssc + BN + b_col[it]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], sc[e], sh[e]), 0.f, bhi[it]);
+        }
+        split4(v[0], v[1], v[2], v[3], hi, lo);
+      }
       *reinterpret_cast<u32x2*>(Bhi + b_lds[it]) = hi;
       if (NP == 3) *reinterpret_cast<u32x2*>(Blo + b_lds[it]) = lo;
     }
@@ -536,6 +534,7 @@ constexpr int x1_lds(int mtw) { return 2 * (2 * (4 * mtw * 16 * 64) + 2 * X1_W_I
 struct XsDgrad1Args {
   const float* G; int ldg; int K;          // dY [M][ldg], K = Cb contracted channels
   int g_bf16;                              // NP == 1 only: dY is rows of bf16 (ldg in elements): staged verbatim, no conversion
+  int g_split;                             // NP == 3 only: dY is SPLIT ROWS (xsplit_dev.h): staged verbatim, no conversion
   int acc;                                 // MASK only: out += x_scale * (gated dz) instead of out = gated dz (deferred norm1 backward: out = the block gradient)
   const unsigned char* Wp;                 // [plane][ksteps][C][64 B]
   float* out; int ldc;
@@ -633,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void xs_dgrad1x1_kernel(XsDgrad1Args p) {
       if ((tid + 512 * u) >> 3 < BM) {
         u32x2 hi, lo;
         if (NP == 1 && p.g_bf16) hi = u32x2{__float_as_uint(rg[set][u][0]), __float_as_uint(rg[set][u][1])};
+        else if (NP == 3 && p.g_split) { hi = u32x2{__float_as_uint(rg[set][u][0]), __float_as_uint(rg[set][u][1])}; lo = u32x2{__float_as_uint(rg[set][u][2]), __float_as_uint(rg[set][u][3])}; }
         else split4(rg[set][u][0], rg[set][u][1], rg[set][u][2], rg[set][u][3], hi, lo);
         *reinterpret_cast<u32x2*>(st + g_lds[u]) = hi;
         if (NP == 3) *reinterpret_cast<u32x2*>(st + X1_G_IMG + g_lds[u]) = lo;
@@ -984,9 +984,14 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
 // output), dense_e3 0.08-0.22 against 0.09-0.25; a persistent workgroup per pixel tile walking its column tiles (stores of tile t draining under
 // tile t + 1): 0.47 / 0.63 / 0.96 and half the speed at dense_e3 (one 80-pixel workgroup per CU).  The f32 kernel: 0.45 / 0.70 / 1.15.
 // =============================================================================================
-constexpr int XF_MTW = 4, XF_NTW = 6, XF_PTMAX = 4 * XF_MTW, XF_BMMAX = XF_PTMAX * 16, XF_BNMAX = 2 * XF_NTW * 16;
-constexpr int XF_X_IMG = XF_BMMAX * 64, XF_W_IMG = XF_BNMAX * 64;
-constexpr int XF_LDS = 3 * XF_X_IMG + 3 * XF_W_IMG;      // one stage: 84 KB
+// MTW = sixteen-pixel tiles per wave row: 4 -> tiles of <= 256 pixels, one 84 KB stage, ONE workgroup per CU.  (Round 5, measured and not kept: MTW = 2 -
+// tiles of <= 128 pixels, a 60 KB stage, TWO workgroups per CU so that one's staging runs beside the other's MFMAs: 9.2 vs 5.8 ms of kernel time per
+// step, 52.6 vs 49.3 ms per step - every workgroup re-stages the 36 KB weight slab for half the pixels, and the L2 -> LDS stream of the weights, not the
+// staging bubble, is what the kernel waits for.)
+constexpr int XF_NTW = 6, XF_BNMAX = 2 * XF_NTW * 16;
+constexpr int XF_W_IMG = XF_BNMAX * 64;
+constexpr int xf_x_img(int mtw) { return 4 * mtw * 16 * 64; }
+constexpr int xf_lds(int mtw) { return 3 * xf_x_img(mtw) + 3 * XF_W_IMG; }
 
 struct XsFwd1Args {
   const float* X; int ldx; int K;          // block buffer [M][ldx], K = Cin contracted channels
@@ -1034,8 +1039,9 @@ __global__ __launch_bounds__(256) void k_xs_pack_w1_fwd(const float* __restrict_
   *reinterpret_cast<u32x4*>(dst + 2 * plane) = u32x4{a2[0], a2[1], b2[0], b2[1]};
 }
 
-template <bool STATS, int NP>
-__global__ __launch_bounds__(512, 2) void xs_fwd1x1_kernel(XsFwd1Args p) {
+template <bool STATS, int NP, int MTW>
+__global__ __launch_bounds__(512, MTW == 4 ? 2 : 4) void xs_fwd1x1_kernel(XsFwd1Args p) {
+  constexpr int XF_MTW = MTW, XF_X_IMG = xf_x_img(MTW);
   extern __shared__ __attribute__((aligned(1024))) unsigned char xf_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, g = lane >> 4;
@@ -1198,8 +1204,10 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   RDM_CHECK_ARG(!a.g_bf16 || a.xsplit == 1, "1x1 wgrad: bf16 gradient rows exist in the one-product (mixed-precision) form only");
   const long gb = ((M - 1) * a.ldg + a.N) * (a.g_bf16 ? 2 : 4), xb = ((M - 1) * a.ldx + a.C) * 4;
   if (gb >= 0xFFFFFFFFL || xb >= 0xFFFFFFFFL) { set_error("split-precision 1x1 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
+  RDM_CHECK_ARG((!a.g_split && !a.x_split) || a.xsplit != 1, "1x1 wgrad: split rows are operands of the three-product form");
+  RDM_CHECK_ARG(!a.x_split || (a.x_scale == nullptr && a.x_shift == nullptr), "1x1 wgrad: split activation rows are already activated (no BatchNorm prologue)");
   XsWgradArgs k{};
-  k.g_bf16 = a.g_bf16;
+  k.g_bf16 = a.g_bf16; k.g_split = a.g_split; k.x_split = a.x_split;
   k.G = a.G; k.ldg = a.ldg; k.N = a.N; k.X = a.Xs; k.ldx = a.ldx; k.C = a.C; k.x_scale = a.x_scale; k.x_shift = a.x_shift;
   k.dW = a.dW; k.ldw = a.ldw; k.M = (int)M; k.g_bytes = (unsigned)gb; k.x_bytes = (unsigned)xb;
   // column tiles of 192 / 144 / 96 channels: the C / 48 units are dealt as evenly as possible over ceil(units / 4) tiles
@@ -1221,7 +1229,7 @@ int launch_xs_wgrad1x1(const WgradArgs& a, hipStream_t s) {
   else k.split_k = (int)std::max<long>(1, std::min<long>(512 / tiles, kslabs / 16));
   if (k.split_k > kslabs) k.split_k = (int)kslabs;
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * a.C, 13);
-  RDM_CENSUS("xs_wgrad1x1_kernel/x%d/%s/%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1");
+  RDM_CENSUS("xs_wgrad1x1_kernel/x%d/%s/%s%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0", k.split_k > 1 ? "splitK" : "split1", a.g_split && a.x_split ? "/rowsGX" : a.g_split ? "/rowsG" : a.x_split ? "/rowsX" : "");
   if (a.xsplit == 1) hipLaunchKernelGGL(xs_wgrad1x1_kernel<1>, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
   else hipLaunchKernelGGL(xs_wgrad1x1_kernel<3>, dim3((unsigned)(tiles * k.split_k)), dim3(256), 0, s, k);
   profile_end(prof, s);
@@ -1320,6 +1328,8 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   XsDgrad1Args k{};
   RDM_CHECK_ARG(!a.acc_scaled || epi == EPI_MASK_STATS, "1x1 dgrad: the accumulating epilogue comes with the gate");
   k.acc = a.acc_scaled;
+  RDM_CHECK_ARG(!a.a_split || np != 1, "1x1 dgrad: split rows are the operand of the three-product form");
+  k.g_split = a.a_split;
   k.G = a.A; k.ldg = a.lda; k.K = K; k.g_bf16 = a.a_bf16; k.Wp = static_cast<const unsigned char*>(ws); k.out = a.out; k.ldc = a.ldc;
   k.X = a.X; k.ldx = a.ldx; k.x_scale = a.x_scale; k.x_shift = a.x_shift; k.stat0 = a.stat0; k.stat1 = a.stat1;
   k.M = (int)M; k.C = C; k.ksteps = ksteps;
@@ -1343,7 +1353,7 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   k.PT = best_pt; k.mtiles = cdiv(M, 16 * best_pt);
   k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad1x1_workspace_bytes(K, C); k.x_bytes = (unsigned)xb;
   void* prof = profile_begin(s, 2.0 * (double)M * C * K, 16);
-  RDM_CENSUS("xs_dgrad1x1_kernel/x%d/%s/%s", np == 1 ? 1 : 3, small ? "px128" : "px320", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE");
+  RDM_CENSUS("xs_dgrad1x1_kernel/x%d/%s/%s%s", np == 1 ? 1 : 3, small ? "px128" : "px320", epi == EPI_MASK_STATS ? "MASK_STATS" : "STORE", a.a_split ? "/rowsG" : "");
   const dim3 grid((unsigned)(k.mtiles * k.ctiles));
 #define RDM_XS_D1B(MASK_, NP_, MTW_, D_) do { \
     RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_dgrad1x1_kernel<MASK_, NP_, MTW_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, x1_lds(MTW_))); \
@@ -1428,9 +1438,10 @@ int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, 
   k.X = a.A; k.ldx = a.lda; k.K = K; k.x_scale = a.a_scale; k.x_shift = a.a_shift; k.Wp = static_cast<const unsigned char*>(ws);
   k.out = a.out; k.ldc = a.ldc; k.stat0 = a.stat0; k.stat1 = a.stat1; k.M = (int)M; k.N = N; k.ksteps = ksteps;
   k.ctiles = cdiv(N / 16, 2 * XF_NTW);
+  constexpr int mtw = 4, slots = 256;
   int best_pt = 1; long best_cost = -1;
-  for (int pt = 1; pt <= XF_PTMAX; ++pt) {
-    const long items = (long)cdiv(M, 16 * pt) * k.ctiles, rounds = (items + 255) / 256;
+  for (int pt = 1; pt <= 4 * mtw; ++pt) {
+    const long items = (long)cdiv(M, 16 * pt) * k.ctiles, rounds = (items + slots - 1) / slots;
     const long cost = rounds * (pt * 16 + 24);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pt = pt; }
   }
@@ -1439,12 +1450,14 @@ int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, 
   void* prof = profile_begin(s, 2.0 * (double)M * N * K, 17);
   RDM_CENSUS("xs_fwd1x1_kernel/x%d/%s/%s", np == 1 ? 1 : 6, a.a_scale ? "bn1" : "bn0", epi == EPI_STORE_STATS ? "STORE_STATS" : "STORE");
   const dim3 grid((unsigned)(k.mtiles * k.ctiles));
-#define RDM_XS_F1(STATS_, NP_) do { \
-    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<STATS_, NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS)); \
-    hipLaunchKernelGGL((xs_fwd1x1_kernel<STATS_, NP_>), grid, dim3(512), XF_LDS, s, k); } while (0)
+#define RDM_XS_F1M(STATS_, NP_, MTW_) do { \
+    RDM_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xs_fwd1x1_kernel<STATS_, NP_, MTW_>), hipFuncAttributeMaxDynamicSharedMemorySize, xf_lds(MTW_))); \
+    hipLaunchKernelGGL((xs_fwd1x1_kernel<STATS_, NP_, MTW_>), grid, dim3(512), xf_lds(MTW_), s, k); } while (0)
+#define RDM_XS_F1(STATS_, NP_) RDM_XS_F1M(STATS_, NP_, 4)
   if (epi == EPI_STORE_STATS) { if (np == 1) RDM_XS_F1(true, 1); else RDM_XS_F1(true, 6); }
   else { if (np == 1) RDM_XS_F1(false, 1); else RDM_XS_F1(false, 6); }
 #undef RDM_XS_F1
+#undef RDM_XS_F1M
   profile_end(prof, s);
   RDM_LAUNCH_OK();
   return 0;

@@ -320,6 +320,8 @@ class DepthEstimationNet(BaseModel):
         self.forward_split = True    # conv1 of dense_e2 / dense_e3 on the three-way-split bf16x6 kernel (RDM_NET_OPT_SPLIT_FWD: float32-equivalent accuracy, measured
                                    # 3-9e-7 of the result's maximum against float64 - the f32 MFMA kernel's own level); False: exact-f32 MFMA
         self.prepack = True          # RDM_NET_OPT_PREPACK: the split kernels' weight images are formed for all layers once per step on the side stream (off the dependent chains)
+        self.wino_x6 = True          # RDM_NET_OPT_WINO_X6: conv2 (3x3) of dense_e2 / dense_e3 forward as Winograd on three-way-split bf16 MFMAs (float32-equivalent; with forward_split)
+        self.split_rows = True       # RDM_NET_OPT_SPLIT_ROWS: dY and relu1(norm1(x)) reach the split conv1 gradient kernels as split rows written once by their producers (bit-identical gradients)
         self.defer_norm1 = True      # RDM_NET_OPT_DEFER_NORM1: the norm1 BatchNorm backward of the blocks on the split kernels without its O(layers^2) elementwise pass (same gradients to f32 rounding)
         self.gemm_bf16 = 0           # 1 (or True): forward and gradient GEMMs, 2: forward only, 3: gradient GEMMs only - MIXED-PRECISION arithmetic (the reference's default `--precision 16`, train.py:11,57-58): every GEMM the two options
                                    # around this line route to the split kernels rounds its operands to bf16 (one MFMA per product, float32 accumulation);
@@ -413,7 +415,7 @@ class DepthEstimationNet(BaseModel):
             self.flatten_parameters()
 
     def _plan(self, B, H, W):
-        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1), bool(self.prepack))
+        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1), bool(self.prepack), bool(self.split_rows), bool(self.wino_x6))
         if self.backward_precision not in ("f32", "bf16x3"):
             raise ValueError("backward_precision must be 'f32' or 'bf16x3'")
         if key not in self._plans:
@@ -428,6 +430,8 @@ class DepthEstimationNet(BaseModel):
             _lib.check(L.rdm_net_set_option(h, 7, 1 if self.forward_split else 0))                      # RDM_NET_OPT_SPLIT_FWD
             _lib.check(L.rdm_net_set_option(h, 10, 1 if self.prepack else 0))                            # RDM_NET_OPT_PREPACK
             _lib.check(L.rdm_net_set_option(h, 9, 1 if self.defer_norm1 else 0))                         # RDM_NET_OPT_DEFER_NORM1
+            _lib.check(L.rdm_net_set_option(h, 11, 1 if self.split_rows else 0))                         # RDM_NET_OPT_SPLIT_ROWS
+            _lib.check(L.rdm_net_set_option(h, 12, 1 if self.wino_x6 else 0))                            # RDM_NET_OPT_WINO_X6
             _lib.check(L.rdm_net_set_option(h, 8, int(self.gemm_bf16)))                          # RDM_NET_OPT_GEMM_BF16
             oh, ow = C.c_int32(), C.c_int32()
             _lib.check(L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)))

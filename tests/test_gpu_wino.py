@@ -43,8 +43,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["f32", "x6"])
 @pytest.mark.parametrize("case", CASES, ids=[f"w{i}" for i in range(len(CASES))])
-def test_wino_forward_vs_float64(case):
+def test_wino_forward_vs_float64(case, kernel):
+    """kernel: f32 = conv3x3_wino_fwd_kernel (f32 MFMA); x6 = conv3x3_wino_x6_kernel (round 5: both transformed operands split three ways, six
+    bf16 MFMAs per float32 product - float32-equivalent).  Same cases, same 2e-5; the x6 kernel is additionally held to 2e-6 (its own level:
+    the dropped terms of the split are 2^-24 relative)."""
     from md_rdm_amd import _lib
     from md_rdm_amd._lib import ConvDesc, check, ptr, stream
     L = _lib.lib()
@@ -62,27 +66,30 @@ def test_wino_forward_vs_float64(case):
     d = ConvDesc(B, H, W, Cb, ld, N, 64, 3, 3, 1, 1, 1, 1)               # output into a 64-wide buffer: a channel slice, as in the block buffers
     yg, wg, scg, shg = y.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
     outs = []
+    wsq = L.rdm_conv3x3_wino_x6_workspace_bytes if kernel == "x6" else L.rdm_conv3x3_wino_workspace_bytes
+    fwd = L.rdm_conv3x3_wino_fwd_x6 if kernel == "x6" else L.rdm_conv3x3_wino_fwd
+    tol = 2e-6 if kernel == "x6" else TOL
     for split, stats in ((1, False), (0, True), (3, True), (0, False)):
-        nb = int(L.rdm_conv3x3_wino_workspace_bytes(Cb, B, H, W, split))
+        nb = int(wsq(Cb, B, H, W, split))
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
         out = torch.full((M, 64), float("nan"), device=dev)
         ssum = torch.zeros(N, dtype=torch.float64, device=dev)
         ssq = torch.zeros_like(ssum)
-        check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out),
-                                     ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), nb, split, stream()))
+        check(fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out),
+                  ptr(ssum) if stats else None, ptr(ssq) if stats else None, ptr(ws), nb, split, stream()))
         got = out.cpu()
         assert torch.isnan(got[:, N:]).all()                               # nothing outside the N-channel slice is written
-        assert rel(got[:, :N].double(), want) < TOL, (split, stats)
+        assert rel(got[:, :N].double(), want) < tol, (split, stats, rel(got[:, :N].double(), want))
         if stats:
             assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
         outs.append((split, got[:, :N].clone()))
     # no atomics anywhere: the same split is bit-reproducible
-    nb = int(L.rdm_conv3x3_wino_workspace_bytes(Cb, B, H, W, 3))
+    nb = int(wsq(Cb, B, H, W, 3))
     ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
     out = torch.full((M, 64), float("nan"), device=dev)
-    check(L.rdm_conv3x3_wino_fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out), None, None, ptr(ws), nb, 3, stream()))
+    check(fwd(C.byref(d), ptr(yg), ptr(wg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(out), None, None, ptr(ws), nb, 3, stream()))
     assert torch.equal(out.cpu()[:, :N], outs[2][1])
-    _RAN.add(case)
+    _RAN.add((kernel, case))
 
 
 

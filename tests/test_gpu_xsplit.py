@@ -268,3 +268,118 @@ def test_xs_fwd1x1_x6_vs_float64(case):
         if stats:
             assert rel(ssum.cpu(), want.sum(0)) < 1e-5 and rel(ssq.cpu(), (want ** 2).sum(0)) < 1e-5
     _RAN.add(("xs_fwd1x1", case))
+
+
+# ---- SPLIT ROWS (round 5): operands converted + split once by their producer, staged verbatim by the 1x1 gradient kernels ----------------------
+def _split_rows_ref(v):
+    """numpy / torch restatement of xsplit_dev.h: per four values [hi x4 | lo x4] bf16, hi = bf16(x) (round to nearest even), lo = bf16(x - hi);
+    returned as the int16 view (M, C / 4, 8) of the row bytes."""
+    hi = v.to(torch.bfloat16)
+    lo = (v - hi.float()).to(torch.bfloat16)
+    M, Cc = v.shape
+    grp = torch.cat([hi.view(M, Cc // 4, 4), lo.view(M, Cc // 4, 4)], dim=2)      # (M, C/4, 8) bf16
+    return grp.view(torch.int16)
+
+
+def test_split_rows_producers_are_bit_exact():
+    """rdm_split_rows_f32 (with and without the BatchNorm + ReLU prologue, ld > C on both sides) and rdm_bn_bwd(accumulate = 2) write exactly the
+    two bf16 values per element the definition gives - the consumers then see the same operand bits as when they split the float32 value themselves."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    M, Cc, ld, ldd = 1037, 144, 160, 148
+    x = torch.randn(M, ld, generator=g) * torch.logspace(-3, 3, ld)                 # a wide dynamic range: the lo parts matter
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    xg, scg, shg = x.to(dev), sc.to(dev), sh.to(dev)
+    for bn in (False, True):
+        dst = torch.full((M, ldd), float("nan"), device=dev)
+        check(L.rdm_split_rows_f32(ptr(xg), ld, ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dst), ldd, M, Cc, stream()))
+        # the kernel's prologue is ONE fused multiply-add per element (fmaf): product exact in float64, one rounding of the sum
+        act = torch.relu((x[:, :Cc].double() * sc.double() + sh.double()).float())
+        want = _split_rows_ref(act if bn else x[:, :Cc].contiguous())
+        got = dst[:, :Cc].contiguous().cpu().view(torch.int16).view(M, Cc // 4, 8)
+        assert torch.equal(got, want), bn
+        assert torch.isnan(dst[:, Cc:]).all()                                       # nothing beyond the row's channels is touched
+    # the norm2 backward writing dY as split rows == the float32 dY, split
+    dz = torch.randn(M, Cc, generator=g).to(dev)
+    s0 = dz.double().sum(0)
+    s1 = (dz.double() * xg[:, :Cc].double()).sum(0)
+    gamma, mean, rstd = (torch.rand(Cc, generator=g) + 0.5).to(dev), xg[:, :Cc].mean(0), 1.0 / (xg[:, :Cc].var(0, unbiased=False) + 1e-5).sqrt()
+    outs = []
+    for mode in (0, 2):
+        dx = torch.full((M, Cc), float("nan"), device=dev)
+        check(L.rdm_bn_bwd(ptr(dx), Cc, ptr(dz), Cc, ptr(xg), ld, ptr(s0), ptr(s1), float(M), ptr(gamma), ptr(mean), ptr(rstd), None, None, M, Cc, mode, 1, stream()))
+        outs.append(dx.cpu())
+    assert torch.equal(outs[1].view(torch.int16).view(M, Cc // 4, 8), _split_rows_ref(outs[0]))
+
+
+@pytest.mark.parametrize("case", [WGRAD1_CASES[1], WGRAD1_CASES[3], WGRAD1_CASES[5]], ids=["rows_w1x1_e2", "rows_w1x1_ragged", "rows_w1x1_e4"])
+def test_xs_wgrad1x1_on_split_rows(case):
+    """The 1x1 weight gradient with its operands handed over as split rows (dY alone; dY and the activated input): same 2e-5 against float64,
+    and the same result as the float32-operand launch up to the order of the K split's atomic adds (the MFMA operands are the same bits)."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, Cc, ld, N, bn = case
+    M = B * H * W
+    g = torch.Generator().manual_seed(4100 + Cc)
+    x = torch.randn(M, ld, generator=g)
+    x[:, Cc:] = float("nan")
+    gy = torch.randn(M, N, generator=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    a = torch.relu(x[:, :Cc] * sc + sh).double()
+    want = gy.double().t() @ a
+    xg, gyg, scg, shg = x.to(dev), gy.to(dev), sc.to(dev), sh.to(dev)
+    gy_rows = torch.empty(M, N, device=dev)
+    check(L.rdm_split_rows_f32(ptr(gyg), N, None, None, ptr(gy_rows), N, M, N, stream()))
+    x_rows = torch.empty(M, Cc, device=dev)                                          # contiguous [M][C]: the plan's layout for this operand
+    check(L.rdm_split_rows_f32(ptr(xg), ld, ptr(scg), ptr(shg), ptr(x_rows), Cc, M, Cc, stream()))
+    d_f32 = ConvDesc(B, H, W, Cc, ld, N, N, 1, 1, 1, 1, 0, 0)
+    d_rows = ConvDesc(B, H, W, Cc, Cc, N, N, 1, 1, 1, 1, 0, 0)
+    ref = torch.zeros(N, Cc, device=dev)
+    check(L.rdm_conv2d_wgrad_x3(C.byref(d_f32), ptr(gyg), ptr(xg), ptr(scg), ptr(shg), ptr(ref), 1, 0, stream()))
+    for flags, desc, xop, bnp in ((0x10, d_f32, xg, True), (0x30, d_rows, x_rows, False)):
+        for split in (0, 1):
+            dw = torch.zeros(N, Cc, device=dev)
+            check(L.rdm_conv2d_wgrad_x3(C.byref(desc), ptr(gy_rows), ptr(xop), ptr(scg) if bnp else None, ptr(shg) if bnp else None, ptr(dw), split, flags, stream()))
+            assert rel(dw.cpu().double(), want) < TOL, (flags, split)
+            if split == 1:                                                           # one workgroup per output tile: no atomics race, same operand bits
+                assert torch.equal(dw, ref), flags
+    assert any(k.startswith("xs_wgrad1x1_kernel/") and k.endswith("/rowsGX") for k in _lib.census())
+    assert L.rdm_conv2d_wgrad_x3(C.byref(d_rows), ptr(gy_rows), ptr(x_rows), ptr(scg), ptr(shg), ptr(ref), 0, 0x30, stream()) < 0      # activated rows + a prologue: refused
+    assert L.rdm_conv2d_wgrad_x3(C.byref(d_rows), ptr(gy_rows), ptr(x_rows), None, None, ptr(ref), 0, 0x31, stream()) < 0              # rows in the bf16-operand mode: refused
+    _RAN.add(("xs_wgrad1x1_rows", case))
+
+
+def test_xs_dgrad1x1_on_split_rows_is_bit_identical():
+    """The 1x1 input gradient fed dY as split rows: the very bits of the float32-operand launch (no atomics on its outputs), gate epilogue included,
+    at dense_e2's and dense_e4's tile instantiations."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    for (B, H, W, K, N, ldx) in ((4, 57, 76, 2736, 336, 384), (16, 15, 19, 720, 432, 2112)):
+        M = B * H * W
+        g = torch.Generator().manual_seed(6100 + N)
+        gy = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)
+        x = torch.randn(M, ldx, generator=g).to(dev)
+        sc, sh = (torch.rand(N, generator=g) + 0.5).to(dev), (torch.randn(N, generator=g) * 0.3).to(dev)
+        rows = torch.empty(M, K, device=dev)
+        check(L.rdm_split_rows_f32(ptr(gy), K, None, None, ptr(rows), K, M, K, stream()))
+        d = ConvDesc(B, H, W, N, N, K, K, 1, 1, 1, 1, 0, 0)
+        wsb = L.rdm_conv1x1_dgrad_x3_workspace_bytes(K, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        out = []
+        for flags, op in ((0, gy), (0x10, rows)):
+            dz = torch.full((M, N), float("nan"), device=dev)
+            s0 = torch.zeros(N, dtype=torch.float64, device=dev)
+            s1 = torch.zeros_like(s0)
+            check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(op), ptr(w), ptr(dz), N, ptr(x), ldx, ptr(sc), ptr(sh), ptr(s0), ptr(s1), ptr(ws), wsb, flags, stream()))
+            out.append(dz)
+        assert torch.equal(out[0], out[1]), (K, N)
+        assert rel(out[1].cpu().double(), (gy.double() @ w.double()).cpu() * (torch.addcmul(sh, x[:, :N], sc) > 0).cpu()) < TOL
+    assert any(k.startswith("xs_dgrad1x1_kernel/") and k.endswith("/rowsG") for k in _lib.census())
