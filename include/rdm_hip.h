@@ -136,6 +136,12 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * activation operand `x` (then already activated: bn_scale = bn_shift = NULL) is given as split rows. */
 #define RDM_X3_DY_SPLIT_ROWS 0x10
 #define RDM_X3_X_SPLIT_ROWS 0x20
+/* 3x3 weight gradient only: `dy` is the FRAME IMAGE rdm_frame_split_rows_f32 wrote - split rows [padded position of the (h + 2) x (w + 2) frames][48]
+ * with zeros on the frames' borders (rdm_frame_split_rows_bytes bytes).  The kernel contracts over padded positions, so a 32-position slab of the
+ * gradient is 6 KB of consecutive bytes, staged verbatim by each of its (column block, K split) workgroups. */
+#define RDM_X3_DY_FRAME_ROWS 0x40
+size_t rdm_frame_split_rows_bytes(int32_t batch, int32_t h, int32_t w);
+int rdm_frame_split_rows_f32(const float* dy, int32_t dy_ld, int32_t channels, int32_t batch, int32_t h, int32_t w, void* dst, rdm_stream_t stream);
 /* dst (split rows, row stride dst_ld floats' worth of bytes) = split(ReLU(bn_scale * src + bn_shift)), or split(src) with bn_scale = bn_shift = NULL:
  * relu1(norm1(x)) of a dense layer (torchvision _DenseLayer reached from network/RDM_Net.py:526-530) as the operand of its conv1 weight gradient. */
 int rdm_split_rows_f32(const float* src, int32_t src_ld, const float* bn_scale, const float* bn_shift, void* dst, int32_t dst_ld, int64_t rows,

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "rdm_candidates_matvec_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
     "rdm_candidates_matvec_bwd": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
     "rdm_split_rows_f32": (C.c_int, [vp, i32, vp, vp, vp, i32, i64, i32, vp]),
+    "rdm_frame_split_rows_bytes": (sz, [i32, i32, i32]),
+    "rdm_frame_split_rows_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "rdm_layout_nchw_to_nhwc_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "rdm_layout_nhwc_to_nchw_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, vp]),
     "rdm_recombine_f64": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

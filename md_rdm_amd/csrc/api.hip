@@ -271,8 +271,9 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
 int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x, const float* bn_scale, const float* bn_shift, float* dw,
                         int32_t split_k, int32_t products, rdm_stream_t stream) {
   RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv2d_wgrad_x3: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
-  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0, x_rows = (products & RDM_X3_X_SPLIT_ROWS) != 0;
-  products &= ~(RDM_X3_DY_SPLIT_ROWS | RDM_X3_X_SPLIT_ROWS);
+  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0, x_rows = (products & RDM_X3_X_SPLIT_ROWS) != 0, dy_frame = (products & RDM_X3_DY_FRAME_ROWS) != 0;
+  products &= ~(RDM_X3_DY_SPLIT_ROWS | RDM_X3_X_SPLIT_ROWS | RDM_X3_DY_FRAME_ROWS);
+  RDM_CHECK_ARG(!dy_frame || (products != 1 && d->kh == 3 && d->kw == 3), "conv2d_wgrad_x3: the frame image is the gradient operand of the 3x3 kernel in the split arithmetic (products 0 / 3)");
   RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv2d_wgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
   RDM_CHECK_ARG(!(dy_rows || x_rows) || (products != 1 && d->kh == 1 && d->kw == 1), "conv2d_wgrad_x3: split rows are operands of the 1x1 kernel in the split arithmetic (products 0 / 3)");
   RDM_CHECK_ARG(!x_rows || (bn_scale == nullptr && bn_shift == nullptr), "conv2d_wgrad_x3: split activation rows are already activated (rdm_split_rows_f32 applied BatchNorm + ReLU)");
@@ -287,7 +288,7 @@ int rdm_conv2d_wgrad_x3(const rdm_conv_desc* d, const float* dy, const float* x,
   a.dW = dw; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
   a.split_k = split_k;
   a.xsplit = products == 1 ? 1 : 3;
-  a.g_split = dy_rows; a.x_split = x_rows;
+  a.g_split = dy_rows; a.x_split = x_rows; a.g_frame = dy_frame;
   if (d->kh == 1 && d->kw == 1) return launch_xs_wgrad1x1(a, stream);
   if (d->kh == 3 && d->kw == 3) return launch_xs_wgrad3x3(a, stream);
   set_error("conv2d_wgrad_x3: no split-precision kernel for a %dx%d convolution", d->kh, d->kw);
@@ -568,6 +569,13 @@ int rdm_split_rows_f32(const float* src, int32_t src_ld, const float* bn_scale, 
                        rdm_stream_t stream) {
   RDM_CHECK_ARG(src && dst && rows > 0 && channels > 0 && src_ld >= channels && dst_ld >= channels, "split_rows: bad argument");
   return launch_split_rows(src, src_ld, bn_scale, bn_shift, dst, dst_ld, rows, channels, stream);
+}
+
+size_t rdm_frame_split_rows_bytes(int32_t batch, int32_t h, int32_t w) { return batch > 0 && h > 0 && w > 0 ? xs_frame_rows_bytes(batch, h, w) : 0; }
+
+int rdm_frame_split_rows_f32(const float* dy, int32_t dy_ld, int32_t channels, int32_t batch, int32_t h, int32_t w, void* dst, rdm_stream_t stream) {
+  RDM_CHECK_ARG(dy && dst && batch > 0 && h > 0 && w > 0 && dy_ld >= channels, "frame_split_rows: bad argument");
+  return launch_frame_split_rows(dy, dy_ld, channels, batch, h, w, dst, stream);
 }
 
 int rdm_layout_nchw_to_nhwc_f32(const float* src, float* dst, int32_t dst_ld, int32_t batch, int32_t channels, int32_t hw, rdm_stream_t stream) {

@@ -229,6 +229,7 @@ struct NetImpl {
   int xs_min_pixels = XS_LAYOUT_MIN_PIXELS;
   bool xs_block(int b) const { return opt_split_bwd && !opt_det && bg[b].M >= xs_min_pixels; }
   int opt_split_rows = 1;      // RDM_NET_OPT_SPLIT_ROWS: dY and relu1(norm1(x)) reach the split 1x1 gradient kernels as SPLIT ROWS (xsplit_dev.h) written once by their producers
+  size_t xsGf = 0;             // frame image of the layer's 48-channel output gradient for the split 3x3 weight gradient (side stream: one at a time)
   size_t xsXh = 0;             // split rows of the activation operand of the layer whose 1x1 weight gradient is running (side stream: one at a time)
   int opt_defer_norm1 = 1;     // RDM_NET_OPT_DEFER_NORM1: see k_bn_bwd_defer (elementwise.hip); blocks on the xs 1x1 dgrad only
   int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
@@ -387,6 +388,10 @@ struct NetImpl {
       for (int b = 0; b < 4; ++b)
         if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) xh = std::max(xh, (size_t)bg[b].M * (size_t)(kBlocks[b].cin + (kBlocks[b].layers - 1) * GROWTH));
       xsXh = a.take<float>(xh);
+      size_t gf = 0;
+      for (int b = 0; b < 4; ++b)
+        if (bg[b].M >= XS_LAYOUT_MIN_PIXELS) gf = std::max(gf, xs_frame_rows_bytes(B, bg[b].H, bg[b].W));
+      xsGf = a.take<unsigned char>(gf);
     }
     for (int b = 0; b < 4; ++b) deferLd = std::max(deferLd, (bg[b].ctot + 63) / 64 * 64);
     deferBC = a.take<float>((size_t)4 * deferLd);
@@ -681,6 +686,13 @@ int backward_block(NetImpl& n, int b, int i_hi, int i_lo, bool join, void* ws, v
       if (n.xs_block_wgrad3(b) && xs_wgrad3x3_supported(xw)) {
         // split-precision direct kernel: accumulates with f32 atomics into the zeroed gradient
         if (!(n.opt_packed3x3 && n.opt_prezeroed) && (rc = zero_f32(dW3, 9 * (size_t)GROWTH * cb, side))) return rc;
+        if (n.opt_split_rows && n.xs_np() == 3) {
+          // the 48-channel gradient as a frame image of split rows, written once: the kernel's 43 column blocks x K splits then stage their
+          // gradient slabs verbatim instead of each deriving every row's pixel and splitting it
+          void* gf = at<unsigned char>(ws, n.xsGf);
+          if ((rc = launch_frame_split_rows(go, g.ctot, GROWTH, n.B, g.H, g.W, gf, side))) return rc;
+          xw.G = static_cast<const float*>(gf); xw.ldg = 48; xw.g_frame = 1;
+        }
         if ((rc = launch_xs_wgrad3x3(xw, side))) return rc;
       } else if (n.wino_wg[b] && !n.opt_no_wino) {
         // Winograd F(3x3, 2x2): writes the gradient (ordered split reduction, no atomics, no zero fill)

@@ -137,6 +137,7 @@ struct WgradArgs {          // dW[tap][n][c] += sum_m G[m][n] * f(Xs[pix(m,tap)]
                                               // three bf16 MFMAs per product; 1 = operands rounded to bf16, one MFMA (the mixed-precision mode)
   int g_bf16;                                 // xsplit == 1 only: G is rows of bf16 (ldg in elements of that type)
   int g_split, x_split;                       // xsplit == 3, 1x1 only: G / Xs are SPLIT ROWS (xsplit_dev.h; Xs then already activated: no x_scale / x_shift)
+  int g_frame;                                // xsplit == 3, 3x3 only: G is the frame image launch_frame_split_rows wrote (xsplit.h)
 };
 
 int launch_conv_fwd(const FwdArgs& a, bool b_kstrided, Epilogue epi, hipStream_t s);

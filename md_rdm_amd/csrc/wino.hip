@@ -356,15 +356,15 @@ __global__ __launch_bounds__(256) void k_wino_reduce(const float* __restrict__ p
 // - the arithmetic of xs_fwd1x1_kernel (xsplit.hip), 6 x 1 / 2.25 = 2.7x the direct convolution's products on a pipe that is 16x faster than the
 // f32 MFMA's.  Replaces conv3x3_wino_fwd_kernel for conv2 of dense_e2 / dense_e3 (torchvision _DenseLayer.conv2, network/RDM_Net.py:526,528).
 //  * K packing: a slab is 16 channels, a v_mfma_f32_16x16x32_bf16 contracts 32 k-slots - two PLANES of the slab side by side.  Three MFMAs
-//    per (position, 16-tile block, 16-output block):   (v0|v1).(u0|u0)   (v0|v2).(u1|u0)   (v0|v1).(u2|u1)   = the six products.
-//  * V image in LDS: one 96-byte row per (position, tile) = [v0: 16 ch | v1 | v2]; fragment (v0|v1) = bytes 16 g .. 16 g + 15 of the row for
-//    k-group g, (v0|v2) the same with +32 for g >= 2.  Row stride 96 B = 6 sixteen-byte slots: the gfx950 ds_read_b128 lane groups
-//    (MI355X_MICROARCH.md, LDS) then hit 16 distinct slots (6 l16 + g mod 16: even slots for even g, odd for odd) - conflict-free without a
-//    swizzle - and so do the producers' 8-byte stores (12 tl + cq mod 32).
+//    per (position, 16-tile block, 16-output block):   (v0|v0).(u0|u1)   (v1|v1).(u0|u1)   (v2|v0).(u0|u2)   = the six products.
+//  * V image in LDS: one 96-byte row per (position, tile) = [v0: 16 ch | v1 | v2]; a fragment's k-group g reads 16 bytes of the row (8 channels of
+//    one plane); lanes of k-groups g and g + 2 of (v0|v0) / (v1|v1) read the SAME bytes - an LDS broadcast.  Row stride 96 B = 6 sixteen-byte
+//    slots: rows l16 = 0 .. 15 start in distinct even slots (6 l16 mod 16), the second k-half in the odd ones - conflict-free without a swizzle -
+//    and so are the producers' 8-byte stores (12 tl + cq mod 32).
 //  * 48 tiles per workgroup (3 consumer M-tiles: 144 accumulator registers - 64 tiles would need 192 + 72 of weight fragments), so the image
 //    (72 KB) is DOUBLE-buffered like the f32 kernel's; 3 producer waves (192 threads = 48 tiles x 4 channel quads) + 4 consumer waves.
-//  * U: k_wino_weight_x6 writes, per (slab, position, 16-output block), the three planes as 512-byte blocks [k-half][n][8 ch]; the three B
-//    fragments are addressed into them per lane ((u0|u0) reads one block twice, the second lane pair hits the same cache lines).
+//  * U: k_wino_weight_x6 writes, per (slab, position, 16-output block), the three planes as 512-byte blocks [k-half][n][8 ch]; the two B
+//    fragments (u0|u1), (u0|u2) are addressed into them per lane: 2 KiB per (position, output block) into registers, 1.5 KiB of it unique.
 // =============================================================================================
 constexpr int TX = 48;                                    // tiles per workgroup
 constexpr int XROW = 96;                                  // bytes per (position, tile) row of the V image
@@ -543,57 +543,72 @@ __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
         __builtin_amdgcn_s_barrier();
       }
     } else {
-      // ---- consumer: positions pos0 .. pos0 + 3; per position 9 B fragments (3 output blocks x 3 MFMAs), per 16-tile block 2 A fragments ----
+      // ---- consumer: positions pos0 .. pos0 + 3.  Per (position, 16-output block) TWO weight fragments, (u0|u1) and (u0|u2); per (position,
+      // 16-tile block) THREE activation fragments from LDS, (v0|v0), (v1|v1), (v2|v0):
+      //     (v0|v0).(u0|u1) + (v1|v1).(u0|u1) + (v2|v0).(u0|u2)  =  v0 u0 + v0 u1 + v1 u0 + v1 u1 + v2 u0 + v0 u2.
+      // (The first form of this kernel duplicated on the WEIGHT side - three 1-KiB fragments per position and output block, 36 KB per position
+      // time of 432 cycles = 85 B/clk per CU through a 64 B/clk L1 - and ran no faster than the f32 kernel: 6.69 vs 6.69 ms per step.  Duplicates
+      // now sit on the LDS side, where two lanes reading one address is a broadcast.)
+      // The weight fragments run TWO positions ahead of their MFMAs through a ring of three register sets: a position is 27 MFMAs = 432 cycles,
+      // less than an L2 round trip under load.  The position walk is unrolled over 12 positions (3 slabs) so that ring slot, accumulator and
+      // LDS buffer indices are all compile-time. ----
       const __amdgpu_buffer_rsrc_t srdU = wsrd(p.U, p.u_bytes);
       const unsigned h = (unsigned)(g & 1), hi2 = (unsigned)(g >> 1);
-      const unsigned ub1 = h * 256u + (unsigned)l16 * 16u;                                         // (u0|u0): block 0 for every k-group
-      const unsigned ub2 = (hi2 ? 0u : (unsigned)XU_BLOCK) + h * 256u + (unsigned)l16 * 16u;       // (u1|u0)
-      const unsigned ub3 = (hi2 ? (unsigned)XU_BLOCK : 2u * XU_BLOCK) + h * 256u + (unsigned)l16 * 16u;   // (u2|u1)
-      bf16x8w bq[2][3][3];
-      auto load_b = [&](int s, int pos, bf16x8w (&b)[3][3]) {
+      const unsigned ub1 = (hi2 ? (unsigned)XU_BLOCK : 0u) + h * 256u + (unsigned)l16 * 16u;        // (u0|u1)
+      const unsigned ub2 = (hi2 ? 2u * XU_BLOCK : 0u) + h * 256u + (unsigned)l16 * 16u;             // (u0|u2)
+      bf16x8w bq[3][3][2];
+      auto load_b = [&](int s, int pos, bf16x8w (&b)[3][2]) {
         const int so = ((s * 16 + pos) * 3) * XU_PNT;
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
           b[nt][0] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub1, so + nt * XU_PNT, 0));
           b[nt][1] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub2, so + nt * XU_PNT, 0));
-          b[nt][2] = __builtin_bit_cast(bf16x8w, __builtin_amdgcn_raw_buffer_load_b128(srdU, (int)ub3, so + nt * XU_PNT, 0));
         }
       };
-      const unsigned a1off = (unsigned)(l16 * XROW + g * 16), a2off = a1off + (hi2 ? 32u : 0u);
-      bf16x8w aq[2][2];
-      auto load_a = [&](const unsigned char* Vb, int pos, int mt, bf16x8w (&a)[2]) {
+      const unsigned arow = (unsigned)(l16 * XROW);
+      const unsigned a0off = arow + h * 16u, a1off = arow + 32u + h * 16u, a2off = arow + (hi2 ? h * 16u : 64u + h * 16u);      // (v0|v0), (v1|v1), (v2|v0)
+      bf16x8w aq[2][3];
+      auto load_a = [&](const unsigned char* Vb, int pos, int mt, bf16x8w (&a)[3]) {
         const unsigned char* r = Vb + (pos * TX + mt * 16) * XROW;
-        a[0] = *reinterpret_cast<const bf16x8w*>(r + a1off);
-        a[1] = *reinterpret_cast<const bf16x8w*>(r + a2off);
+        a[0] = *reinterpret_cast<const bf16x8w*>(r + a0off);
+        a[1] = *reinterpret_cast<const bf16x8w*>(r + a1off);
+        a[2] = *reinterpret_cast<const bf16x8w*>(r + a2off);
       };
+      const int total = (s_end - s_begin) * 4;                       // positions this wave walks: q -> slab s_begin + (q >> 2), position pos0 + (q & 3)
       load_b(s_begin, pos0, bq[0]);
+      load_b(s_begin, pos0 + 1, bq[1]);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      for (int s = s_begin; s < s_end; ++s) {
-        const unsigned char* Vb = wx_smem + ((s - s_begin) & 1) * XIMG;
-        load_a(Vb, pos0, 0, aq[0]);
+      for (int base = 0; base < total; base += 12) {
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-          if (pp < 3) load_b(s, pos0 + pp + 1, bq[(pp + 1) & 1]);
-          else load_b(min(s + 1, s_end - 1), pos0, bq[0]);
+        for (int u = 0; u < 12; ++u) {
+          const int q = base + u;
+          if (q < total) {                                           // (wave-uniform)
+            const int pp = u & 3;
+            const unsigned char* Vb = wx_smem + ((q >> 2) & 1) * XIMG;
+            if (q + 2 < total) load_b(s_begin + ((q + 2) >> 2), pos0 + ((u + 2) & 3), bq[(u + 2) % 3]);
+            if (pp == 0) load_a(Vb, pos0, 0, aq[0]);
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt) {
-            const int cur = (pp * 3 + mt) & 1;
-            if (mt < 2) load_a(Vb, pos0 + pp, mt + 1, aq[cur ^ 1]);
-            else if (pp < 3) load_a(Vb, pos0 + pp + 1, 0, aq[cur ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < 3; ++mt) {
+              const int cur = (pp * 3 + mt) & 1;
+              if (mt < 2) load_a(Vb, pos0 + pp, mt + 1, aq[cur ^ 1]);
+              else if (pp < 3) load_a(Vb, pos0 + pp + 1, 0, aq[cur ^ 1]);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {                       // smallest terms first: (v0 u2 + v1 u1), (v0 u1 + v2 u0), (v0 u0 + v1 u0)
-              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[pp & 1][nt][2], acc[pp][mt][nt], 0, 0, 0);
-              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][1], bq[pp & 1][nt][1], acc[pp][mt][nt], 0, 0, 0);
-              acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[pp & 1][nt][0], acc[pp][mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < 3; ++nt) {                       // small terms first
+                acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][2], bq[u % 3][nt][1], acc[pp][mt][nt], 0, 0, 0);      // v2 u0 + v0 u2
+                acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][1], bq[u % 3][nt][0], acc[pp][mt][nt], 0, 0, 0);      // v1 u0 + v1 u1
+                acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[u % 3][nt][0], acc[pp][mt][nt], 0, 0, 0);      // v0 u0 + v0 u1
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (pp == 3) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+            }
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
       }
     }
   }

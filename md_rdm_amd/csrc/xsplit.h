@@ -15,6 +15,9 @@ bool xs_dgrad1x1_supported(const FwdArgs& a);
 size_t xs_dgrad1x1_workspace_bytes(int K, int C);
 int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, hipStream_t s, int np = 3, bool prepacked = false);
 // 3x3 / stride 1 / pad 1 weight gradient with <= 48 output channels: operands and meaning of launch_conv_wgrad (dW pre-zeroed, accumulated)
+// frame image of the gradient operand (a.g_frame = 1, a.G = the image): split rows [padded position][48] with zeros on the frames' borders
+size_t xs_frame_rows_bytes(int B, int H, int W);
+int launch_frame_split_rows(const float* G, int ldg, int N, int B, int H, int W, void* dst, hipStream_t s);
 bool xs_wgrad3x3_supported(const WgradArgs& a);
 int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s);
 // 1x1 / stride 1 FORWARD with a three-way split (six bf16 MFMAs per product: float32-equivalent); FwdArgs as launch_conv_fwd takes them

@@ -773,6 +773,8 @@ struct XsWgrad3Args {
   float* dW; long wtap; int ldw; int N;    // packed gradient [tap][n][c]
   int B, H, W;
   int nslab, split, ahead;                 // slabs of 32 padded positions; K splits; slabs the activation ring runs ahead (= behind): ceil((W + 3) / 32)
+  int g_frame;                             // NP == 3: G is the FRAME image of the gradient (launch_frame_split_rows): split rows [padded position][48], zeros on the frame's
+                                           // border - a slab's gradient rows are 6 KB of consecutive bytes, staged verbatim (no position arithmetic, no split)
   unsigned g_bytes, y_bytes;
 };
 
@@ -854,7 +856,9 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
-      const unsigned off = pi < 24 ? pix_off(s * 32 + 4 * rg + kq, p.ldg, 16 * ct + 4 * jq, 16 * ct + 4 * jq < p.N) : XOOB;
+      unsigned off;
+      if (NP == 3 && p.g_frame) off = (pi < 24 && s >= 0) ? (unsigned)(s * 32 + 4 * rg + kq) * 192u + (unsigned)((16 * ct + 4 * jq) * 4) : XOOB;      // past the image: out of range -> zeros
+      else off = pi < 24 ? pix_off(s * 32 + 4 * rg + kq, p.ldg, 16 * ct + 4 * jq, 16 * ct + 4 * jq < p.N) : XOOB;
       rgv[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdG, (int)off, 0, 0));
     }
   };
@@ -865,7 +869,8 @@ __global__ __launch_bounds__(256, 2) void xs_wgrad3x3_kernel(XsWgrad3Args p) {
       const int pi = grp + 16 * it, rg = pi / 3, ct = pi - 3 * rg;
       if (pi < 24) {
         u32x2 hi, lo;
-        split4(rgv[set][it][0], rgv[set][it][1], rgv[set][it][2], rgv[set][it][3], hi, lo);
+        if (NP == 3 && p.g_frame) { hi = u32x2{__float_as_uint(rgv[set][it][0]), __float_as_uint(rgv[set][it][1])}; lo = u32x2{__float_as_uint(rgv[set][it][2]), __float_as_uint(rgv[set][it][3])}; }
+        else split4(rgv[set][it][0], rgv[set][it][1], rgv[set][it][2], rgv[set][it][3], hi, lo);
         const int row = 4 * rg + kq, rb = row >> 3, pr = (row & 7) ^ ((rb & 1) << 2);
         const unsigned a = (unsigned)(256 * (rb * 3 + ct) + 32 * pr + 8 * jq);
         *reinterpret_cast<u32x2*>(gb + a) = hi;
@@ -1368,6 +1373,31 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   return 0;
 }
 
+// Frame image of a 48-channel gradient for xs_wgrad3x3_kernel: dst[u][48] (split rows, xsplit_dev.h) for the padded positions u of the (H + 2) x (W + 2)
+// frames of all images, rounded up to whole 32-position slabs; zeros on the border, past the last frame and in channels >= N.
+__global__ __launch_bounds__(256) void k_frame_split_rows(const float* __restrict__ G, int ldg, int N, int B, int H, int W, long upad, u32x4* __restrict__ dst) {
+  const int Wp = W + 2, PP = (H + 2) * Wp;
+  const long total = upad * 12;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long u = idx / 12;
+    const int c = (int)(idx - u * 12) * 4;
+    const int b = (int)(u / PP), rem = (int)(u - (long)b * PP), yp = rem / Wp, xp = rem - yp * Wp;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (b < B && yp >= 1 && yp <= H && xp >= 1 && xp <= W && c < N) v = *reinterpret_cast<const f32x4*>(G + ((long)(b * H + yp - 1) * W + xp - 1) * ldg + c);
+    dst[idx] = split_row4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+size_t xs_frame_rows_bytes(int B, int H, int W) { return (size_t)(((long)B * (H + 2) * (W + 2) + 31) / 32 * 32) * 192; }
+
+int launch_frame_split_rows(const float* G, int ldg, int N, int B, int H, int W, void* dst, hipStream_t s) {
+  RDM_CHECK_ARG(N >= 4 && N <= 48 && N % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)dst & 15) == 0, "frame_split_rows: N (%d) a multiple of 4 up to 48, ldg a multiple of 4, operands 16-byte aligned", N);
+  const long upad = ((long)B * (H + 2) * (W + 2) + 31) / 32 * 32;
+  hipLaunchKernelGGL(k_frame_split_rows, dim3((unsigned)std::min<long>(cdiv(upad * 12, 256), 256 * 16)), dim3(256), 0, s, G, ldg, N, B, H, W, upad, static_cast<u32x4*>(dst));
+  RDM_LAUNCH_OK();
+  return 0;
+}
+
 bool xs_wgrad3x3_supported(const WgradArgs& a) {
   const ConvGeom& g = a.g;
   return g.KH == 3 && g.KW == 3 && g.SH == 1 && g.SW == 1 && g.PH == 1 && g.PW == 1 && g.H == g.Ho && g.W == g.Wo && g.dir == 1 && a.N <= 48 && a.N % 4 == 0 &&
@@ -1378,9 +1408,11 @@ int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
   RDM_CHECK_ARG(xs_wgrad3x3_supported(a), "split-precision 3x3 wgrad: needs a 3x3 / stride 1 / pad 1 convolution with N (%d) <= 48, N and C (%d) multiples of 4, W (%d) <= 93", a.N, a.C, a.g.W);
   RDM_CHECK_ARG(a.ldg % 4 == 0 && a.ldx % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.G & 15) == 0 && ((uintptr_t)a.Xs & 15) == 0, "split-precision 3x3 wgrad: strides multiples of 4 floats, operands 16-byte aligned");
   const long M = (long)a.g.B * a.g.H * a.g.W;
-  const long gb = ((M - 1) * a.ldg + a.N) * 4, yb = ((M - 1) * a.ldx + a.C) * 4;
+  RDM_CHECK_ARG(!a.g_frame || a.xsplit != 1, "3x3 wgrad: the frame image is an operand of the three-product form");
+  const long gb = a.g_frame ? (long)xs_frame_rows_bytes(a.g.B, a.g.H, a.g.W) : ((M - 1) * a.ldg + a.N) * 4, yb = ((M - 1) * a.ldx + a.C) * 4;
   if (gb >= 0xFFFFFFFFL || yb >= 0xFFFFFFFFL) { set_error("split-precision 3x3 wgrad: operand extent >= 4 GiB is not supported by the 32-bit buffer addressing"); return RDM_ERR_UNSUPPORTED; }
   XsWgrad3Args k{};
+  k.g_frame = a.g_frame;
   k.G = a.G; k.ldg = a.ldg; k.Y = a.Xs; k.ldy = a.ldx; k.C = a.C; k.y_scale = a.x_scale; k.y_shift = a.x_shift;
   k.dW = a.dW; k.wtap = a.wtap; k.ldw = a.ldw; k.N = a.N; k.B = a.g.B; k.H = a.g.H; k.W = a.g.W;
   const long U = (long)a.g.B * (a.g.H + 2) * (a.g.W + 2);
@@ -1398,7 +1430,7 @@ int launch_xs_wgrad3x3(const WgradArgs& a, hipStream_t s) {
   k.split = best;
   k.g_bytes = (unsigned)gb; k.y_bytes = (unsigned)yb;
   void* prof = profile_begin(s, 2.0 * (double)M * a.N * 9.0 * a.C, 15);
-  RDM_CENSUS("xs_wgrad3x3_kernel/x%d/%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0");
+  RDM_CENSUS("xs_wgrad3x3_kernel/x%d/%s%s", a.xsplit == 1 ? 1 : 3, a.x_scale ? "bn1" : "bn0", a.g_frame ? "/frameG" : "");
   if (a.xsplit == 1) hipLaunchKernelGGL(xs_wgrad3x3_kernel<1>, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
   else hipLaunchKernelGGL(xs_wgrad3x3_kernel<3>, dim3((unsigned)cblocks, (unsigned)k.split), dim3(256), 0, s, k);
   profile_end(prof, s);

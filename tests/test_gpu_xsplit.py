@@ -180,6 +180,13 @@ def test_xs_dgrad1x1_vs_float64(case):
     _RAN.add(("xs_dgrad1x1", case))
 
 
+def F_pad_frame(gy, B, H, W):
+    """(B, H, W, N) -> (B (H + 2) (W + 2), 48): the padded-frame ordering xs_wgrad3x3_kernel contracts over, zeros on the border and in channels >= N"""
+    import torch.nn.functional as F
+    N = gy.shape[-1]
+    return F.pad(gy, (0, 48 - N, 1, 1, 1, 1)).reshape(-1, 48).contiguous()
+
+
 def _ref3x3_wgrad(gy, a):
     import torch.nn.functional as F
     B, H, W, N = gy.shape
@@ -218,11 +225,28 @@ def test_xs_wgrad3x3_vs_float64(case):
     want = _ref3x3_wgrad(gy.double(), a)
     d = ConvDesc(B, H, W, Cc, ld, N, ldg, 3, 3, 1, 1, 1, 1)
     xg, gyg, scg, shg = x.to(dev), gyb.to(dev), sc.to(dev), sh.to(dev)
+    ref1 = None
     for split in (0, 1, 3):
         dw = torch.zeros(9, N, Cc, device=dev)
         check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(gyg), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, 0, stream()))
         err = rel(dw.cpu().double(), want)
         assert err < TOL, (split, err)
+        if split == 1:
+            ref1 = dw
+    # the gradient operand as a FRAME IMAGE of split rows (round 5: what the plan hands the kernel): zeros on the frames' borders, the same two bf16
+    # values per element - same tolerance, and with one workgroup per output tile (split 1: no race between atomic adds) the very same bits
+    fb = int(L.rdm_frame_split_rows_bytes(B, H, W))
+    frame = torch.full((fb // 4,), float("nan"), device=dev)
+    check(L.rdm_frame_split_rows_f32(ptr(gyg), ldg, N, B, H, W, ptr(frame), stream()))
+    fi = frame.view(torch.int16).view(-1, 12, 8).cpu()
+    gp = F_pad_frame(gyb[..., :N], B, H, W)                                      # (U, 48) float32 with zero borders / zero channels >= N
+    assert torch.equal(fi[:gp.shape[0]], _split_rows_ref(gp)) and int(fi[gp.shape[0]:].abs().max() if fi.shape[0] > gp.shape[0] else 0) == 0
+    for split in (0, 1):
+        dw = torch.zeros(9, N, Cc, device=dev)
+        check(L.rdm_conv2d_wgrad_x3(C.byref(d), ptr(frame), ptr(xg), ptr(scg) if bn else None, ptr(shg) if bn else None, ptr(dw), split, 0x40, stream()))
+        assert rel(dw.cpu().double(), want) < TOL, ("frame", split)
+        if split == 1:
+            assert torch.equal(dw, ref1)
     _RAN.add(("xs_wgrad3x3", case))
 
 
