@@ -178,7 +178,9 @@ int rdm_conv3x3_wino_fwd(const rdm_conv_desc* d, const float* x, const float* w_
 /* The same convolution on the bf16 matrix pipe with float32-EQUIVALENT arithmetic (round 5): both transformed operands split three ways
  * (v = v0 + v1 + v2 in bf16, 24 significant bits), six bf16 products per float32 product, float32 accumulation - the arithmetic of
  * rdm_conv1x1_fwd_x6 applied to the 16 position GEMMs of F(2x2, 3x3).  Same operands, meaning and tolerance as rdm_conv3x3_wino_fwd
- * (tests/test_gpu_wino.py holds both to 2e-5 of the output's maximum against float64); ~2x its speed at dense_e2 / dense_e3 sizes. */
+ * (tests/test_gpu_wino.py holds both to 2e-5 of the output's maximum against float64, this one also to 5e-6).  Measured at dense_e2 / dense_e3
+ * sizes: no faster than the f32 kernel - both are bound by the transform producers and the per-workgroup prologue / epilogue of the K split, not by
+ * the matrix pipe (profiles/r05_wino_x6_ablation.txt) - so the plan keeps the f32 kernel by default (RDM_NET_OPT_WINO_X6). */
 size_t rdm_conv3x3_wino_x6_workspace_bytes(int32_t channels, int32_t batch, int32_t h, int32_t w, int32_t split_k);
 int rdm_conv3x3_wino_fwd_x6(const rdm_conv_desc* d, const float* x, const float* w_packed, const float* bn_scale, const float* bn_shift, float* y,
                             double* stat_sum, double* stat_sq, void* workspace, size_t workspace_bytes, int32_t split_k, rdm_stream_t stream);
@@ -334,7 +336,7 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *   RDM_NET_OPT_SPLIT_ROWS       (default 1) float32 arithmetic on the split kernels: the norm2 BatchNorm backward writes dY as split rows and relu1(norm1(x))
  *                                is activated + split once per layer (rdm_split_rows_f32) - the conv1 input / weight gradient kernels stage both operands
  *                                verbatim instead of converting and splitting them per tile.  Bit-identical gradients (the same two bf16 values per element).
- *   RDM_NET_OPT_WINO_X6          (default 1, with RDM_NET_OPT_SPLIT_FWD) the Winograd 3x3 forward of the blocks with >= 8 192 pixels runs the bf16x6 kernel
+ *   RDM_NET_OPT_WINO_X6          (default 0; with RDM_NET_OPT_SPLIT_FWD) the Winograd 3x3 forward of the blocks with >= 8 192 pixels runs the bf16x6 kernel
  *                                (rdm_conv3x3_wino_fwd_x6: float32-equivalent accuracy on the bf16 matrix pipe) instead of the f32 MFMA one.
  *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic (the reference's default --precision 16, train.py:11,57-58): every launch that
  *                                RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels rounds its operands to bf16 instead (ONE bf16

@@ -201,7 +201,7 @@ struct NetImpl {
   // stream at the start of forward) and one scratch for the per-split partial outputs
   bool wino_fwd[4] = {false, false, false, false}, wino_wg[4] = {false, false, false, false};
   int wino_split[4] = {1, 1, 1, 1}, wino_split_x6[4] = {1, 1, 1, 1};
-  int opt_wino_x6 = 1;         // RDM_NET_OPT_WINO_X6: the Winograd forward of those blocks on the bf16x6 kernel (float32-equivalent, bf16 matrix pipe)
+  int opt_wino_x6 = 0;         // RDM_NET_OPT_WINO_X6: the Winograd forward of those blocks on the bf16x6 kernel (float32-equivalent, bf16 matrix pipe)
   bool wino_x6(int b) const { return opt_wino_x6 && opt_split_fwd && !opt_det && wino_fwd[b]; }
   size_t winoPartial = 0, winoPartialFloats = 0;
   size_t winoVy = 0, winoVyFloats = 0, winoQ = 0, winoQFloats = 0;     // weight-gradient scratch (side stream: one launch at a time)

@@ -437,9 +437,16 @@ struct WinoX6Args {
   float* out; int ldc; int N;
   int B, H, W, TH, TW, T;
   int split;
+  int abl;                 // development builds only: timing-only ablations (RDM_WX6_ABL; results wrong by construction): 1 every gather of a thread from one pixel,
+                           // 2 no weight loads in the loop, 4 no MFMAs, 8 no split, 16 no LDS stores (profiles/r05_wino_x6_ablation.txt)
   unsigned a_bytes, u_bytes;
 };
 
+#ifdef RDM_DEV_VARIANTS
+#define WX6_ABL(bit) (p.abl & (bit))
+#else
+#define WX6_ABL(bit) false
+#endif
 template <bool BNRELU>
 __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char wx_smem[];      // V double buffer: 2 x XIMG; reused by the epilogue
@@ -485,6 +492,10 @@ __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
             voff[i * 4 + j] = ok ? (unsigned)((b * p.H + y) * p.W + x) * (unsigned)(p.lda * 4) + (unsigned)(cq * 16) : WOOB;
             hi[i * 4 + j] = ok ? __builtin_inff() : 0.f;
           }
+        if (WX6_ABL(1)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) voff[q] = voff[5];
+        }
       }
       const __amdgpu_buffer_rsrc_t srdA = wsrd(p.A, p.a_bytes);
       const unsigned rowoff = (unsigned)(tl * XROW + cq * 8);
@@ -520,11 +531,14 @@ __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
 #pragma unroll
           for (int pos = 0; pos < 16; ++pos) {
             u32x2 p0, p1, p2;
-            wsplit3x4(rv[0][pos], rv[1][pos], rv[2][pos], rv[3][pos], p0, p1, p2);
+            if (WX6_ABL(8)) { p0 = u32x2{__float_as_uint(rv[0][pos]), __float_as_uint(rv[1][pos])}; p1 = u32x2{__float_as_uint(rv[2][pos]), __float_as_uint(rv[3][pos])}; p2 = p0; }
+            else wsplit3x4(rv[0][pos], rv[1][pos], rv[2][pos], rv[3][pos], p0, p1, p2);
             unsigned char* row = Vb + pos * (TX * XROW) + rowoff;
+            if (!WX6_ABL(16)) {
             *reinterpret_cast<u32x2*>(row) = p0;
             *reinterpret_cast<u32x2*>(row + 32) = p1;
             *reinterpret_cast<u32x2*>(row + 64) = p2;
+            } else asm volatile("" :: "v"(p0), "v"(p1), "v"(p2));
           }
         }
       };
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
           if (q < total) {                                           // (wave-uniform)
             const int pp = u & 3;
             const unsigned char* Vb = wx_smem + ((q >> 2) & 1) * XIMG;
-            if (q + 2 < total) load_b(s_begin + ((q + 2) >> 2), pos0 + ((u + 2) & 3), bq[(u + 2) % 3]);
+            if (q + 2 < total && !WX6_ABL(2)) load_b(s_begin + ((q + 2) >> 2), pos0 + ((u + 2) & 3), bq[(u + 2) % 3]);
             if (pp == 0) load_a(Vb, pos0, 0, aq[0]);
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
@@ -596,6 +610,7 @@ __global__ __launch_bounds__(448, 2) void conv3x3_wino_x6_kernel(WinoX6Args p) {
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int nt = 0; nt < 3; ++nt) {                       // small terms first
+                if (WX6_ABL(4)) { asm volatile("" :: "v"(aq[cur][0]), "v"(aq[cur][1]), "v"(aq[cur][2]), "v"(bq[u % 3][nt][0]), "v"(bq[u % 3][nt][1])); continue; }
                 acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][2], bq[u % 3][nt][1], acc[pp][mt][nt], 0, 0, 0);      // v2 u0 + v0 u2
                 acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][1], bq[u % 3][nt][0], acc[pp][mt][nt], 0, 0, 0);      // v1 u0 + v1 u1
                 acc[pp][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[cur][0], bq[u % 3][nt][0], acc[pp][mt][nt], 0, 0, 0);      // v0 u0 + v0 u1
@@ -1000,6 +1015,10 @@ int launch_conv3x3_wino_fwd(const WinoConv& a, hipStream_t s) {
     k.A = a.A; k.lda = a.lda; k.C = a.C; k.a_scale = a.a_scale; k.a_shift = a.a_shift; k.U = reinterpret_cast<const unsigned char*>(a.U);
     k.out = split > 1 ? a.partial : a.out; k.ldc = a.ldc; k.N = a.N;
     k.B = a.B; k.H = a.H; k.W = a.W; k.TH = TH; k.TW = TW; k.T = T; k.split = split; k.a_bytes = (unsigned)ab; k.u_bytes = (unsigned)wino_u_bytes(a.C, true);
+#ifdef RDM_DEV_VARIANTS
+    static const int abl_env = getenv("RDM_WX6_ABL") ? atoi(getenv("RDM_WX6_ABL")) : 0;
+    k.abl = abl_env;
+#endif
     void* prof = profile_begin(s, 2.0 * M * a.N * 9.0 * a.C, 18);
     RDM_CENSUS("conv3x3_wino_x6_kernel/%s/%s", a.a_scale ? "bn1" : "bn0", split > 1 ? "PARTIAL" : (a.stat0 ? "STORE+stats" : "STORE"));
     dim3 grid((unsigned)cdiv(T, TX), (unsigned)split);

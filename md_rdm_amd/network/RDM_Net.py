@@ -320,7 +320,9 @@ class DepthEstimationNet(BaseModel):
         self.forward_split = True    # conv1 of dense_e2 / dense_e3 on the three-way-split bf16x6 kernel (RDM_NET_OPT_SPLIT_FWD: float32-equivalent accuracy, measured
                                    # 3-9e-7 of the result's maximum against float64 - the f32 MFMA kernel's own level); False: exact-f32 MFMA
         self.prepack = True          # RDM_NET_OPT_PREPACK: the split kernels' weight images are formed for all layers once per step on the side stream (off the dependent chains)
-        self.wino_x6 = True          # RDM_NET_OPT_WINO_X6: conv2 (3x3) of dense_e2 / dense_e3 forward as Winograd on three-way-split bf16 MFMAs (float32-equivalent; with forward_split)
+        self.wino_x6 = False         # RDM_NET_OPT_WINO_X6: conv2 (3x3) of dense_e2 / dense_e3 forward as Winograd on three-way-split bf16 MFMAs (float32-equivalent; with forward_split).
+                                     # Correct (2e-6 of the maximum vs float64) but NOT faster than the f32 MFMA kernel at these sizes (7.1 vs 6.7 ms per step): the kernel is bound by
+                                     # its producers and the per-workgroup prologue / epilogue of the deep K split, not by the matrix pipe (profiles/r05_wino_x6_ablation.txt)
         self.split_rows = True       # RDM_NET_OPT_SPLIT_ROWS: dY and relu1(norm1(x)) reach the split conv1 gradient kernels as split rows written once by their producers (bit-identical gradients)
         self.defer_norm1 = True      # RDM_NET_OPT_DEFER_NORM1: the norm1 BatchNorm backward of the blocks on the split kernels without its O(layers^2) elementwise pass (same gradients to f32 rounding)
         self.gemm_bf16 = 0           # 1 (or True): forward and gradient GEMMs, 2: forward only, 3: gradient GEMMs only - MIXED-PRECISION arithmetic (the reference's default `--precision 16`, train.py:11,57-58): every GEMM the two options
