@@ -425,26 +425,29 @@ int launch_bn_bwd_apply(float* dst, int ldd, const float* dz, int ldz, const flo
 // torchvision _DenseLayer) is formed and split ONCE per layer instead of once per 128-channel gradient tile inside the GEMM.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ src, int lds_, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    float* __restrict__ dst, int ldd, long M, int C4) {
-  const long total = M * C4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long m = idx / C4;
-    const int c = (int)(idx - m * C4) * 4;
-    f32x4e v = *reinterpret_cast<const f32x4e*>(src + m * lds_ + c);
+                                                    float* __restrict__ dst, int ldd, int M, int C4) {
+  // a thread keeps its channel quad (and its BatchNorm coefficients) and walks rows: no division per element
+  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  if (c >= C4 * 4) return;
+  f32x4e sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (scale) { sc = *reinterpret_cast<const f32x4e*>(scale + c); sh = *reinterpret_cast<const f32x4e*>(shift + c); }
+  for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < M; m += gridDim.y * 4) {
+    f32x4e v = *reinterpret_cast<const f32x4e*>(src + (long)m * lds_ + c);
     if (scale) {
-      const f32x4e sc = *reinterpret_cast<const f32x4e*>(scale + c), sh = *reinterpret_cast<const f32x4e*>(shift + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
     }
-    *reinterpret_cast<xs_u32x4*>(dst + m * ldd + c) = split_row4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<xs_u32x4*>(dst + (long)m * ldd + c) = split_row4(v[0], v[1], v[2], v[3]);
   }
 }
 
 int launch_split_rows(const float* src, int ld_src, const float* scale, const float* shift, void* dst, int ld_dst, long M, int C, hipStream_t s) {
   RDM_CHECK_ARG(C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "split_rows: channels / strides multiples of 4, operands 16-byte aligned");
   RDM_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0, "split_rows: scale and shift go together, 16-byte aligned");
-  const long total = M * (C / 4);
-  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)std::min<long>(cdiv(total, 256), 256 * 16)), dim3(256), 0, s, src, ld_src, scale, shift, static_cast<float*>(dst), ld_dst, M, C / 4);
+  RDM_CHECK_ARG(M > 0 && M < (1L << 31), "split_rows: rows");
+  const int gx = cdiv(C / 4, 64);
+  const int gy = (int)std::min<long>(cdiv(M, 4), std::max(1, 4096 / gx));
+  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, src, ld_src, scale, shift, static_cast<float*>(dst), ld_dst, (int)M, C / 4);
   RDM_LAUNCH_OK();
   return 0;
 }

@@ -1375,16 +1375,18 @@ int launch_xs_dgrad1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
 
 // Frame image of a 48-channel gradient for xs_wgrad3x3_kernel: dst[u][48] (split rows, xsplit_dev.h) for the padded positions u of the (H + 2) x (W + 2)
 // frames of all images, rounded up to whole 32-position slabs; zeros on the border, past the last frame and in channels >= N.
-__global__ __launch_bounds__(256) void k_frame_split_rows(const float* __restrict__ G, int ldg, int N, int B, int H, int W, long upad, u32x4* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_frame_split_rows(const float* __restrict__ G, int ldg, int N, int B, int H, int W, int upad, u32x4* __restrict__ dst) {
+  // 252 threads = 21 positions x 12 channel quads per pass; a position's frame coordinates through float reciprocals (exact below 2^21 positions,
+  // as in xs_wgrad3x3_kernel) - the first form of this kernel did 64-bit divisions per element and took 172 us per launch for 14 MB
   const int Wp = W + 2, PP = (H + 2) * Wp;
-  const long total = upad * 12;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long u = idx / 12;
-    const int c = (int)(idx - u * 12) * 4;
-    const int b = (int)(u / PP), rem = (int)(u - (long)b * PP), yp = rem / Wp, xp = rem - yp * Wp;
+  const float rPP = 1.0f / (float)PP, rWp = 1.0f / (float)Wp;
+  const int t = threadIdx.x, pl = (int)((unsigned)t * 2731u >> 15), q = t - pl * 12;          // t / 12, t % 12 for t < 252
+  if (t >= 252) return;
+  for (int u = blockIdx.x * 21 + pl; u < upad; u += gridDim.x * 21) {
+    const int b = (int)(((float)u + 0.5f) * rPP), rem = u - b * PP, yp = (int)(((float)rem + 0.5f) * rWp), xp = rem - yp * Wp;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (b < B && yp >= 1 && yp <= H && xp >= 1 && xp <= W && c < N) v = *reinterpret_cast<const f32x4*>(G + ((long)(b * H + yp - 1) * W + xp - 1) * ldg + c);
-    dst[idx] = split_row4(v[0], v[1], v[2], v[3]);
+    if (b < B && yp >= 1 && yp <= H && xp >= 1 && xp <= W && 4 * q < N) v = *reinterpret_cast<const f32x4*>(G + ((long)(b * H + yp - 1) * W + xp - 1) * ldg + 4 * q);
+    dst[(long)u * 12 + q] = split_row4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -1393,7 +1395,8 @@ size_t xs_frame_rows_bytes(int B, int H, int W) { return (size_t)(((long)B * (H 
 int launch_frame_split_rows(const float* G, int ldg, int N, int B, int H, int W, void* dst, hipStream_t s) {
   RDM_CHECK_ARG(N >= 4 && N <= 48 && N % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)dst & 15) == 0, "frame_split_rows: N (%d) a multiple of 4 up to 48, ldg a multiple of 4, operands 16-byte aligned", N);
   const long upad = ((long)B * (H + 2) * (W + 2) + 31) / 32 * 32;
-  hipLaunchKernelGGL(k_frame_split_rows, dim3((unsigned)std::min<long>(cdiv(upad * 12, 256), 256 * 16)), dim3(256), 0, s, G, ldg, N, B, H, W, upad, static_cast<u32x4*>(dst));
+  RDM_CHECK_ARG(upad < (1L << 21), "frame_split_rows: %ld padded positions (the float-reciprocal frame arithmetic is exact below 2^21)", upad);
+  hipLaunchKernelGGL(k_frame_split_rows, dim3((unsigned)std::min<long>(cdiv(upad, 21), 256 * 16)), dim3(256), 0, s, G, ldg, N, B, H, W, (int)upad, static_cast<u32x4*>(dst));
   RDM_LAUNCH_OK();
   return 0;
 }
