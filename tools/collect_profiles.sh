@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU call that regenerates the round's profiles (run on the GPU box from the repo root:  gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04'):
+# One GPU call that regenerates the round's profiles (run on the GPU box from the repo root:  gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r05'):
 # the default bench line, kernel trace + stats, phase timeline, decoder trace, the two PMC passes (HBM-side bytes per kernel) and the in-process A/B
 # of the split-precision kernels.  Outputs land in gpurun_out/<tag>/; copy what is to be judged into profiles/ (names in profiles/README.md).
 TAG=${1:-rNN}
@@ -7,6 +7,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
+cp bench_detail.json $O/bench_detail.json          # the full record of THAT run (the profiling runs below overwrite bench_detail.json)
 echo bench done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o train -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline --no-extra-configs > $O/trace.log 2>&1
 echo trace done
