@@ -219,6 +219,9 @@ def ptr(t):
 
 
 def stream():
+    """The caller's current HIP stream.  Through the raw query: ``torch.cuda.current_stream()`` builds a Stream object and asks the runtime for the device
+    count on the way (hipGetDeviceCount, ~20 us per call on this stack - ~100 C-ABI calls per training step sit in the host-paced phases between the
+    native forward and backward, where the GPU waits for the host; tools/host_lead.py)."""
     import torch
 
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -309,8 +309,14 @@ struct XsDgrad3Args {
   int out_bf16;                            // NP == 1 only: `out` is rows of bf16 (ldc in elements): the consumers round to bf16 anyway
   int nslots, plane_bytes;                 // slot 0 = zeros, slot 1 + s = pixel m0 - (W + 1) + s, s < XD_BM + 2 (W + 1)
   int mtiles, ctiles;                      // pixel tiles, 128-channel column tiles
+  int abl;                                 // development builds only (RDM_XD3_ABL): timing-only ablations, results wrong by construction: 1 no gate loads, 2 no stores, 4 no MFMA loop, 8 no statistics (profiles/r05_dgrad3x3_ablation.txt)
   unsigned g_bytes, w_bytes, x_bytes, o_bytes;
 };
+#ifdef RDM_DEV_VARIANTS
+#define XD3_ABL(bit) (p.abl & (bit))
+#else
+#define XD3_ABL(bit) false
+#endif
 
 __global__ __launch_bounds__(256) void k_xs_pack_w3_dgrad(const float* __restrict__ w, long wtap, int ldw, int Cb, unsigned char* __restrict__ Wf) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
     frag(0, 0, gq[0]);
 #pragma unroll
     for (int j = 0; j < XD_KSTEPS; ++j) {
+      if (XD3_ABL(4)) break;
       if (j + 1 < XD_KSTEPS) load_w(j + 1, wf[(j + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < XD_MT; ++i) {
@@ -471,7 +478,10 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
 #pragma unroll
       for (int i0 = 0; i0 < XD_MT; i0 += XD_EB) {
         f32x4 xv[XD_EB];
-        if (MASK) {
+        if (MASK && XD3_ABL(1)) {
+#pragma unroll
+          for (int u = 0; u < XD_EB; ++u) xv[u] = acc[i0 + u][t];
+        } else if (MASK) {
 #pragma unroll
           for (int u = 0; u < XD_EB; ++u)
             xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (int)((cok && m0 + (i0 + u) * 16 + l16 < p.M) ? vx : XOOB), (i0 + u) * 16 * p.ldx * 4, 0));
@@ -493,10 +503,11 @@ __global__ __launch_bounds__(256, 2) void xs_dgrad3x3_kernel(XsDgrad3Args p) {
           if (NP == 1 && p.out_bf16) {
             const bf16x2 lo2 = {(__bf16)v[0], (__bf16)v[1]}, hi2 = {(__bf16)v[2], (__bf16)v[3]};
             if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + (long)(m0 + i * 16 + l16) * p.ldc + c4) = u32x2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
-          } else if (ok) *reinterpret_cast<f32x4*>(p.out + (long)(m0 + i * 16 + l16) * p.ldc + c4) = v;
+          } else if (ok && !XD3_ABL(2)) *reinterpret_cast<f32x4*>(p.out + (long)(m0 + i * 16 + l16) * p.ldc + c4) = v;
+          else if (XD3_ABL(2)) asm volatile("" :: "v"(v));
         }
       }
-      if (MASK) {
+      if (MASK && !XD3_ABL(8)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float a = s0[e], b = s1[e];
@@ -1005,8 +1016,14 @@ struct XsFwd1Args {
   float* out; int ldc;
   double* stat0; double* stat1;
   int M, N, ksteps, PT, mtiles, ctiles;
+  int abl;                                 // development builds only (RDM_XF1_ABL): timing-only ablations, results wrong by construction: 1 no stores, 2 no MFMAs, 4 no statistics, 8 no split arithmetic (profiles/r05_fwd1x1_ablation.txt)
   unsigned x_bytes, w_bytes;
 };
+#ifdef RDM_DEV_VARIANTS
+#define XF1_ABL(bit) (p.abl & (bit))
+#else
+#define XF1_ABL(bit) false
+#endif
 
 __device__ __forceinline__ void split3x4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
   const bf16x2 a01 = {(__bf16)v[0], (__bf16)v[1]}, a23 = {(__bf16)v[2], (__bf16)v[3]};
@@ -1103,7 +1120,8 @@ __global__ __launch_bounds__(512, MTW == 4 ? 2 : 4) void xs_fwd1x1_kernel(XsFwd1
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
         }
         u32x2 p0, p1, p2;
-        split3x4(v, p0, p1, p2);
+        if (XF1_ABL(8)) { p0 = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; p1 = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])}; p2 = p0; }
+        else split3x4(v, p0, p1, p2);
         *reinterpret_cast<u32x2*>(Xi + x_lds[u]) = p0;
         if (NP == 6) {
           *reinterpret_cast<u32x2*>(Xi + XF_X_IMG + x_lds[u]) = p1;
@@ -1147,6 +1165,7 @@ __global__ __launch_bounds__(512, MTW == 4 ? 2 : 4) void xs_fwd1x1_kernel(XsFwd1
 #pragma unroll
         for (int i = 0; i < XF_MTW; ++i)
           if (i < npw) {                                        // smallest terms first
+            if (XF1_ABL(2)) { asm volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(x0[i]), "v"(x1[i]), "v"(x2[i])); continue; }
             if (NP == 6) {
               acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[i], acc[i][t], 0, 0, 0);
               acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x0[i], acc[i][t], 0, 0, 0);
@@ -1173,11 +1192,12 @@ __global__ __launch_bounds__(512, MTW == 4 ? 2 : 4) void xs_fwd1x1_kernel(XsFwd1
       const bool ok = nok && i < npw && m < p.M;
       const f32x4 v = acc[i][t];
       if (ok) {
-        *reinterpret_cast<f32x4*>(p.out + (long)m * p.ldc + n4) = v;       // (plain global stores: see the note in xs_dgrad3x3_kernel)
+        if (!XF1_ABL(1)) *reinterpret_cast<f32x4*>(p.out + (long)m * p.ldc + n4) = v;       // (plain global stores: see the note in xs_dgrad3x3_kernel)
+        else asm volatile("" :: "v"(v));
         if (STATS) { s0 += v; s1 += v * v; }
       }
     }
-    if (STATS) {
+    if (STATS && !XF1_ABL(4)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float a = s0[e], b = s1[e];
@@ -1283,6 +1303,9 @@ int launch_xs_dgrad3x3(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes
   k.nslots = 1 + XD_BM + 2 * (a.g.W + 1);
   k.plane_bytes = (k.nslots * XD_SLOT + 1023) & ~1023;
   k.mtiles = cdiv(M, XD_BM); k.ctiles = cdiv(Cb, XD_BN);
+#ifdef RDM_DEV_VARIANTS
+  if (getenv("RDM_XD3_ABL")) k.abl = atoi(getenv("RDM_XD3_ABL"));
+#endif
   k.g_bytes = (unsigned)gb; k.w_bytes = (unsigned)xs_dgrad3x3_workspace_bytes(Cb); k.x_bytes = (unsigned)xb; k.o_bytes = (unsigned)ob;
   const int lds = xs_dgrad3_lds_bytes(a.g.W);
   // persistent workgroups: as many as are resident at once (2 per CU while two image pairs fit the 160 KB of LDS), each with an equal share of the items
@@ -1473,6 +1496,9 @@ int launch_xs_fwd1x1(const FwdArgs& a, Epilogue epi, void* ws, size_t ws_bytes, 
   k.X = a.A; k.ldx = a.lda; k.K = K; k.x_scale = a.a_scale; k.x_shift = a.a_shift; k.Wp = static_cast<const unsigned char*>(ws);
   k.out = a.out; k.ldc = a.ldc; k.stat0 = a.stat0; k.stat1 = a.stat1; k.M = (int)M; k.N = N; k.ksteps = ksteps;
   k.ctiles = cdiv(N / 16, 2 * XF_NTW);
+#ifdef RDM_DEV_VARIANTS
+  if (getenv("RDM_XF1_ABL")) k.abl = atoi(getenv("RDM_XF1_ABL"));
+#endif
   constexpr int mtw = 4, slots = 256;
   int best_pt = 1; long best_cost = -1;
   for (int pt = 1; pt <= 4 * mtw; ++pt) {
