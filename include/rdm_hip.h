@@ -140,6 +140,10 @@ int rdm_conv2d_wgrad_ex(const rdm_conv_desc* d, const float* dy, const float* x,
  * with zeros on the frames' borders (rdm_frame_split_rows_bytes bytes).  The kernel contracts over padded positions, so a 32-position slab of the
  * gradient is 6 KB of consecutive bytes, staged verbatim by each of its (column block, K split) workgroups. */
 #define RDM_X3_DY_FRAME_ROWS 0x40
+/* rdm_conv1x1_dgrad_x3 with a mask only: the epilogue ADDS mask_scale[c] * (gated dz) into dx (the block gradient, dx_ld = its row stride) instead
+ * of storing the gated dz - the a * dz term of the norm1 backward taken by the input gradient itself (mask_scale = gamma * rstd is the forward's
+ * BatchNorm scale); the b * x + c terms follow through rdm_bn_bwd_defer.  network/RDM_Net.py:526 (autograd of torchvision _DenseLayer.norm1). */
+#define RDM_X3_ACC_SCALED 0x80
 size_t rdm_frame_split_rows_bytes(int32_t batch, int32_t h, int32_t w);
 int rdm_frame_split_rows_f32(const float* dy, int32_t dy_ld, int32_t channels, int32_t batch, int32_t h, int32_t w, void* dst, rdm_stream_t stream);
 /* dst (split rows, row stride dst_ld floats' worth of bytes) = split(ReLU(bn_scale * src + bn_shift)), or split(src) with bn_scale = bn_shift = NULL:
@@ -260,6 +264,17 @@ int rdm_bn_bwd_reduce(float* dz, int32_t dz_ld, const float* x, int32_t x_ld, co
 int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const float* x, int32_t x_ld, const double* sum_dz,
                const double* sum_dz_x, double count, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
                float* dbeta, int64_t rows, int32_t channels, int32_t accumulate, int32_t training, rdm_stream_t stream);
+/* Deferred norm1 backward of a dense block (the plan's default on the split kernels; RDM_NET_OPT_DEFER_NORM1).  The BatchNorm backward of layer
+ * i adds a dz + b x + c over ALL its input channels; a dz is added by the 1x1 input gradient (RDM_X3_ACC_SCALED), and since x - the block buffer's
+ * channel - is the same for every layer reading it, the (b, c) of the layers walked so far are SUMMED per channel and applied once, when a channel's
+ * gradient is read next.  One call per layer, last layer first: from the layer's reductions (sum_dz, sum_dz_x as rdm_bn_bwd takes them) it forms
+ * (b, c) with rdm_bn_bwd's arithmetic, writes b_out / c_out [channels] = b_in / c_in + (b, c) (ping-pong buffers; b_in = c_in = zeros at the block's
+ * last layer), dgamma / dbeta (either may be NULL), and applies g[:, slice_c0 : slice_c0 + slice_n] += b_out x + c_out to the slice whose gradient
+ * the caller reads next (the 48 channels the layer below produced; after the first layer the block's input channels). */
+int rdm_bn_bwd_defer(float* g, int32_t g_ld, const float* x, int32_t x_ld, const double* sum_dz, const double* sum_dz_x, double count,
+                     const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, const float* b_in,
+                     const float* c_in, float* b_out, float* c_out, int64_t rows, int32_t channels, int32_t slice_c0, int32_t slice_n,
+                     int32_t training, rdm_stream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1): x (B,H,W,C) contiguous -> y (B,Ho,Wo,C) with pixel stride y_ld; argmax (B,Ho,Wo,C) uint8 = winning
  * tap r*3+s (first maximum in scan order, as ATen).  Backward is the gather form: dx (B,H,W,C) contiguous, every element written. */
 int rdm_maxpool3s2_fwd(const float* x, float* y, int32_t y_ld, uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t channels,

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "rdm_bn_finalize": (C.c_int, [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "rdm_bn_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, vp, i64, i32, vp, vp, vp]),
     "rdm_bn_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, vp, f64, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "rdm_bn_bwd_defer": (C.c_int, [vp, i32, vp, i32, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "rdm_maxpool3s2_fwd": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "rdm_maxpool3s2_bwd": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "rdm_padavgpool2_fwd": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),

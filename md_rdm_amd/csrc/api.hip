@@ -252,9 +252,10 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   int rc = geom_from_desc(d, &g);
   if (rc) return rc;
   RDM_CHECK_ARG(dy && w && dx, "conv1x1_dgrad_x3: NULL operand");
-  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0;
-  products &= ~RDM_X3_DY_SPLIT_ROWS;
+  const int dy_rows = (products & RDM_X3_DY_SPLIT_ROWS) != 0, acc_scaled = (products & RDM_X3_ACC_SCALED) != 0;
+  products &= ~(RDM_X3_DY_SPLIT_ROWS | RDM_X3_ACC_SCALED);
   RDM_CHECK_ARG(products == 0 || products == 1 || products == 3, "conv1x1_dgrad_x3: products (%d) must be 0 / 3 (split precision) or 1 (bf16 operands)", (int)products);
+  RDM_CHECK_ARG(!acc_scaled || mask_x, "conv1x1_dgrad_x3: the scaled accumulating epilogue belongs to the masked form");
   RDM_CHECK_ARG(!dy_rows || products != 1, "conv1x1_dgrad_x3: split rows are an operand of the split arithmetic (products 0 / 3)");
   RDM_CHECK_ARG(!mask_x || (mask_scale && mask_shift && stat_a && stat_b), "conv1x1_dgrad_x3: mask needs scale, shift and both statistics");
   ConvGeom gd{d->batch, g.Ho, g.Wo, d->in_h, d->in_w, d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w, -1};
@@ -264,6 +265,7 @@ int rdm_conv1x1_dgrad_x3(const rdm_conv_desc* d, const float* dy, const float* w
   a.out = dx; a.ldc = dx_ld; a.M = d->batch * d->in_h * d->in_w; a.N = d->in_c;
   a.X = mask_x; a.ldx = mask_ld; a.x_scale = mask_scale; a.x_shift = mask_shift; a.stat0 = stat_a; a.stat1 = stat_b;
   a.a_split = dy_rows;
+  a.acc_scaled = acc_scaled;
   if (!xs_dgrad1x1_supported(a)) { set_error("conv1x1_dgrad_x3: no split-precision kernel for this convolution (1x1 / stride 1, in_c a multiple of 16 and <= 2304)"); return RDM_ERR_UNSUPPORTED; }
   return launch_xs_dgrad1x1(a, mask_x ? EPI_MASK_STATS : EPI_STORE, workspace, workspace_bytes, stream, products == 1 ? 1 : 3);
 }
@@ -506,6 +508,19 @@ int rdm_bn_bwd(float* dx, int32_t dx_ld, const float* dz, int32_t dz_ld, const f
   RDM_CHECK_ARG(accumulate >= 0 && accumulate <= 2, "bn_bwd: accumulate (%d) must be 0 (write), 1 (add) or 2 (write as split rows)", (int)accumulate);
   return launch_bn_bwd_apply(dx, dx_ld, dz, dz_ld, x, x_ld, sum_dz, sum_dz_x, count, gamma, save_mean, save_rstd, dgamma, dbeta, (int)rows, channels,
                              accumulate == 1, training, stream, false, accumulate == 2);
+}
+
+int rdm_bn_bwd_defer(float* g, int32_t g_ld, const float* x, int32_t x_ld, const double* sum_dz, const double* sum_dz_x, double count,
+                     const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, const float* b_in,
+                     const float* c_in, float* b_out, float* c_out, int64_t rows, int32_t channels, int32_t slice_c0, int32_t slice_n,
+                     int32_t training, rdm_stream_t stream) {
+  if (int rc = check_nhwc(g, g_ld, channels, "bn_bwd_defer(g)")) return rc;
+  if (int rc = check_nhwc(x, x_ld, channels, "bn_bwd_defer(x)")) return rc;
+  RDM_CHECK_ARG(sum_dz && sum_dz_x && gamma && save_mean && save_rstd && b_in && c_in && b_out && c_out && rows > 0 && rows < (1L << 31) && count >= 1,
+                "bn_bwd_defer: bad argument");
+  RDM_CHECK_ARG(b_in != b_out && c_in != c_out, "bn_bwd_defer: the running sums are ping-pong buffers (in != out)");
+  return launch_bn_bwd_defer(g, g_ld, x, x_ld, sum_dz, sum_dz_x, count, gamma, save_mean, save_rstd, dgamma, dbeta, b_in, c_in, b_out, c_out, (int)rows,
+                             channels, slice_c0, slice_n, training, stream);
 }
 
 int rdm_maxpool3s2_fwd(const float* x, float* y, int32_t y_ld, uint8_t* argmax, int32_t batch, int32_t h, int32_t w, int32_t channels,

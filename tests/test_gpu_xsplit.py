@@ -407,3 +407,87 @@ def test_xs_dgrad1x1_on_split_rows_is_bit_identical():
         assert torch.equal(out[0], out[1]), (K, N)
         assert rel(out[1].cpu().double(), (gy.double() @ w.double()).cpu() * (torch.addcmul(sh, x[:, :N], sc) > 0).cpu()) < TOL
     assert any(k.startswith("xs_dgrad1x1_kernel/") and k.endswith("/rowsG") for k in _lib.census())
+
+
+@pytest.mark.parametrize("geom", [(2, 9, 11, 96, 3, 96), (4, 15, 19, 384, 4, 720)], ids=["small", "dense_e4_width"])
+def test_deferred_norm1_backward_operator_level(geom):
+    """The deferred norm1 backward of a dense block (autograd of torchvision _DenseLayer.norm1 reached from network/RDM_Net.py:526-530) at OPERATOR
+    level, with fixed inputs and a data dependence that makes the ORDER of application matter: layer i's bottleneck gradient is formed from the
+    block gradient of the 48 channels it produced (dY_i = G[:, cin_i : cin_i + 48] @ R_i), so every b x + c term of the layers above must have
+    reached that slice by the time layer i reads it.  The deferred sequence (1x1 input gradient with RDM_X3_ACC_SCALED, then rdm_bn_bwd_defer with
+    its ping-pong sums, last layer first, a stage boundary in the middle) against the per-layer sequence it replaces (plain gate epilogue, then
+    rdm_bn_bwd with accumulate = 1) to 1e-5 of the block gradient's maximum, and both against a float64 evaluation to 2e-5 x layers."""
+    from md_rdm_amd import _lib
+    from md_rdm_amd._lib import ConvDesc, check, ptr, stream
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, C0, layers, Cb = geom
+    GROWTH, M = 48, B * H * W
+    ctot = C0 + layers * GROWTH
+    g = torch.Generator().manual_seed(8800 + C0)
+    x = torch.randn(M, ctot, generator=g)
+    G0 = torch.randn(M, ctot, generator=g)
+    Ws = [torch.randn(Cb, C0 + i * GROWTH, generator=g) / Cb ** 0.5 for i in range(layers)]
+    Rs = [torch.randn(GROWTH, Cb, generator=g) / GROWTH ** 0.5 for i in range(layers)]
+    gam = [torch.rand(C0 + i * GROWTH, generator=g) + 0.5 for i in range(layers)]
+    bet = [torch.randn(C0 + i * GROWTH, generator=g) * 0.3 for i in range(layers)]
+    mean, rstd, sc, sh = [], [], [], []
+    for i in range(layers):
+        cin = C0 + i * GROWTH
+        xd = x[:, :cin].double()
+        mu = xd.mean(0); var = xd.var(0, unbiased=False)
+        rs = 1.0 / torch.sqrt(var + 1e-5)
+        mean.append(mu.float()); rstd.append(rs.float())
+        sc.append((gam[i].double() * rs).float()); sh.append((bet[i].double() - mu * gam[i].double() * rs).float())
+    # ---- float64 evaluation (what k_bn_bwd_apply<true> computes, layer by layer, last layer first)
+    Gr = G0.double().clone()
+    want_dg, want_db = [None] * layers, [None] * layers
+    for i in reversed(range(layers)):
+        cin = C0 + i * GROWTH
+        dY = Gr[:, cin:cin + GROWTH] @ Rs[i].double()
+        xd = x[:, :cin].double()
+        mask = (torch.addcmul(sh[i].double(), xd, sc[i].double()) > 0).double()
+        dz = (dY @ Ws[i].double()) * mask
+        xhat = (xd - mean[i].double()) * rstd[i].double()
+        want_dg[i] = (dz * xhat).sum(0); want_db[i] = dz.sum(0)
+        Gr[:, :cin] += gam[i].double() * rstd[i].double() * (dz - dz.mean(0) - xhat * (dz * xhat).mean(0))
+    xg = x.to(dev)
+    todev = lambda lst: [t.to(dev) for t in lst]
+    Wg, Rg, gamg, meang, rstdg, scg, shg = todev(Ws), todev(Rs), todev(gam), todev(mean), todev(rstd), todev(sc), todev(sh)
+    wsb = max(int(L.rdm_conv1x1_dgrad_x3_workspace_bytes(Cb, C0 + i * GROWTH)) for i in range(layers))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    results = {}
+    for mode in ("per_layer", "deferred"):
+        G = G0.to(dev).clone()
+        dgs, dbs = [None] * layers, [None] * layers
+        ld = (ctot + 63) // 64 * 64
+        bc = torch.zeros(2, 2, ld, device=dev)                            # [parity][b | c][channel]: zeros = the sums above the block's last layer
+        for i in reversed(range(layers)):
+            cin = C0 + i * GROWTH
+            dY = (G[:, cin:cin + GROWTH] @ Rg[i]).contiguous()           # reads the slice: it must be final here
+            s0 = torch.zeros(cin, dtype=torch.float64, device=dev); s1 = torch.zeros_like(s0)
+            dgs[i] = torch.empty(cin, device=dev); dbs[i] = torch.empty(cin, device=dev)
+            d = ConvDesc(B, H, W, cin, cin, Cb, Cb, 1, 1, 1, 1, 0, 0)
+            if mode == "per_layer":
+                dz = torch.full((M, cin), float("nan"), device=dev)
+                check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(dY), ptr(Wg[i]), ptr(dz), cin, ptr(xg), ctot, ptr(scg[i]), ptr(shg[i]), ptr(s0), ptr(s1), ptr(ws), wsb, 0, stream()))
+                check(L.rdm_bn_bwd(ptr(G), ctot, ptr(dz), cin, ptr(xg), ctot, ptr(s0), ptr(s1), float(M), ptr(gamg[i]), ptr(meang[i]), ptr(rstdg[i]), ptr(dgs[i]), ptr(dbs[i]), M, cin, 1, 1, stream()))
+            else:
+                check(L.rdm_conv1x1_dgrad_x3(C.byref(d), ptr(dY), ptr(Wg[i]), ptr(G), ctot, ptr(xg), ctot, ptr(scg[i]), ptr(shg[i]), ptr(s0), ptr(s1), ptr(ws), wsb, 0x80, stream()))
+                b_in, b_out = bc[(i + 1) & 1], bc[i & 1]
+                c0, n = (cin - GROWTH, GROWTH) if i > 0 else (0, cin)
+                check(L.rdm_bn_bwd_defer(ptr(G), ctot, ptr(xg), ctot, ptr(s0), ptr(s1), float(M), ptr(gamg[i]), ptr(meang[i]), ptr(rstdg[i]), ptr(dgs[i]), ptr(dbs[i]),
+                                         ptr(b_in[0]), ptr(b_in[1]), ptr(b_out[0]), ptr(b_out[1]), M, cin, c0, n, 1, stream()))
+            if i == layers // 2:
+                torch.cuda.synchronize()                                  # a stage boundary of the staged backward (i_hi, i_lo): the running sums live across it
+        torch.cuda.synchronize()
+        results[mode] = (G.cpu().double(), [t.cpu().double() for t in dgs], [t.cpu().double() for t in dbs])
+    scale = Gr.abs().max().item()
+    for mode, (G, dgs, dbs) in results.items():
+        assert torch.isfinite(G).all(), mode
+        assert (G - Gr).abs().max().item() / scale < TOL * layers, (mode, (G - Gr).abs().max().item() / scale)
+        for i in range(layers):
+            assert rel(dgs[i], want_dg[i]) < TOL * layers and rel(dbs[i], want_db[i]) < TOL * layers, (mode, i)
+    assert (results["deferred"][0] - results["per_layer"][0]).abs().max().item() / scale < 1e-5
+    # the slices the deferred form finalises late differ from "never applied" by far more than the tolerance: the check above has teeth
+    assert (Gr - G0.double())[:, :C0].abs().max().item() / scale > 1e-2
