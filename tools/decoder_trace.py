@@ -29,7 +29,18 @@ def report(name, ks, layers):
         d = by.setdefault(n, [0, 0]); d[0] += 1; d[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for n, (c, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:8]:
         print(f"    {n:48s} x{c:4d}  {d / 1e3:8.1f} us  ({d / c / 1e3:.1f} us each)")
+    by = {}
+    for r in ks:
+        if r["Stream_Id"] == main: continue
+        n = r["Kernel_Name"].replace("void ", "").replace("rdm::", "").split("(")[0][:48]
+        d = by.setdefault(n, [0, 0]); d[0] += 1; d[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    for n, (c, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:6]:
+        print(f"    (side) {n:41s} x{c:4d}  {d / 1e3:8.1f} us  ({d / c / 1e3:.1f} us each)")
+e4f = phase(lambda n: "k_trans_pool(" in n, lambda n: "k_trans_pool(" in n, nth_start=1)
+report("dense_e4 forward (36 layers + its transition conv)", e4f, 36)
 fwd = phase(lambda n: "k_trans_pool(" in n, lambda n: "k_dorn_fwd" in n, nth_start=2)
 report("decoder forward (24 layers)", fwd, 24)
 bwd = phase(lambda n: "k_dorn_bwd" in n, lambda n: "k_trans_pool_bwd_reduce" in n)
 report("decoder backward (24 layers + head)", bwd, 24)
+e4b = phase(lambda n: "k_trans_pool_bwd_reduce" in n, lambda n: "k_trans_pool_bwd_reduce" in n, nth_start=0)
+report("dense_e4 backward (transition + 36 layers)", e4b, 36)
