@@ -55,6 +55,7 @@ def main():
                     help="bf16x3 (default, what the package ships): the gradient GEMMs of dense_e2 / dense_e3 on the split-precision kernels; f32: exact-f32 MFMA everywhere")
     ap.add_argument("--forward-split", type=int, default=1, help="1 (default, what the package ships): conv1 of dense_e2 / e3 on the three-way-split bf16x6 forward kernel (float32-equivalent); 0: f32 MFMA")
     ap.add_argument("--split-rows", type=int, default=1, help="1 (default, what the package ships): dY and relu1(norm1(x)) reach the split conv1 gradient kernels as split rows written once by their producers; 0: each kernel converts and splits per tile (A/B)")
+    ap.add_argument("--fuse-stats3", type=int, default=1, help="1 (default, what the package ships): the K-split 3x3 conv of the few-pixel blocks takes its output's channel statistics in the same launch; 0: separate column reduction (A/B)")
     ap.add_argument("--wino-x6", type=int, default=0, help="0 (default, what the package ships): the f32 MFMA Winograd kernel; 1: conv2 of dense_e2 / e3 forward as Winograd on three-way-split bf16 MFMAs (float32-equivalent; measured not faster)")
     ap.add_argument("--gemm-bf16", type=int, default=0, choices=[0, 1, 2, 3],
                     help="MIXED-PRECISION arithmetic (the reference's default --precision 16): the GEMMs the two options above route to the split kernels round their operands to bf16, "
@@ -251,6 +252,7 @@ def bench_train(args, B, H, W, with_cpu_baseline, metric="depth-maps/sec NYU 228
     model.gemm_bf16 = int(args.gemm_bf16)
     model.split_rows = bool(args.split_rows)
     model.wino_x6 = bool(args.wino_x6)
+    model.fuse_stats3 = bool(args.fuse_stats3)
     filler.fill_state_dict(model.state_dict())
     model = model.to(dev)
     model.train()

@@ -353,6 +353,9 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                verbatim instead of converting and splitting them per tile.  Bit-identical gradients (the same two bf16 values per element).
  *   RDM_NET_OPT_WINO_X6          (default 0; with RDM_NET_OPT_SPLIT_FWD) the Winograd 3x3 forward of the blocks with >= 8 192 pixels runs the bf16x6 kernel
  *                                (rdm_conv3x3_wino_fwd_x6: float32-equivalent accuracy on the bf16 matrix pipe) instead of the f32 MFMA one.
+ *   RDM_NET_OPT_FUSE_STATS3      (default 1) training forward of the few-pixel blocks (dense_e4, decoder d_1): the K-split 3x3 convolution of a layer takes the
+ *                                channel statistics of its 48 outputs in the same launch - the last split of a pixel tile to arrive reduces the finished tile -
+ *                                instead of a separate column reduction on the dependent chain (0: the separate pass; the values differ only in summation order).
  *   RDM_NET_OPT_GEMM_BF16        mixed-precision arithmetic (the reference's default --precision 16, train.py:11,57-58): every launch that
  *                                RDM_NET_OPT_SPLIT_BWD / RDM_NET_OPT_SPLIT_FWD route to the split kernels rounds its operands to bf16 instead (ONE bf16
  *                                MFMA per product, float32 accumulation).  value 1 = forward and gradient GEMMs, 2 = forward only, 3 = gradient GEMMs
@@ -360,7 +363,7 @@ int rdm_net_output_hw(const rdm_net* net, int32_t* h, int32_t* w);
  *                                GEMMs in this mode the per-layer dZ -> dY scratch tensor is kept as bf16.  Not the parity configuration: tolerance
  *                                stated in tests/test_gpu_mixed.py. */
 typedef enum rdm_net_option { RDM_NET_OPT_PACKED_3X3 = 1, RDM_NET_OPT_GRADS_PREZEROED = 2, RDM_NET_OPT_DIRECT_3X3 = 3, RDM_NET_OPT_DETERMINISTIC = 4,
-                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9, RDM_NET_OPT_PREPACK = 10, RDM_NET_OPT_SPLIT_ROWS = 11, RDM_NET_OPT_WINO_X6 = 12 } rdm_net_option;
+                              RDM_NET_OPT_JOIN_PER_SEGMENT = 5, RDM_NET_OPT_SPLIT_BWD = 6, RDM_NET_OPT_SPLIT_FWD = 7, RDM_NET_OPT_GEMM_BF16 = 8, RDM_NET_OPT_DEFER_NORM1 = 9, RDM_NET_OPT_PREPACK = 10, RDM_NET_OPT_SPLIT_ROWS = 11, RDM_NET_OPT_WINO_X6 = 12, RDM_NET_OPT_FUSE_STATS3 = 13 } rdm_net_option;
 int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value);
 
 /* x: (B,3,H,W) float32 NCHW; logits: (B,180,h,w) float32 NCHW (conv2 output, RDM_Net.py:159). */

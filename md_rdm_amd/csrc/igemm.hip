@@ -606,6 +606,55 @@ __global__ __launch_bounds__(256, 4) void conv3x3_halo_kernel(FwdArgs p) {
     }
   }
   conv_epilogue<MT, NT, EPI>(p, acc, m0, n0, wrow, 0, l16, g);
+  if (RAWBN && EPI == EPI_ATOMIC && p.tickets != nullptr) {
+    // Channel statistics of the finished tile by the LAST K split to arrive (round 5: the separate column reduction was a 7-14 us launch on the
+    // dependent chain of every few-pixel layer).  Ordering as in conv3x3_act_bf16_kernel (bf16.hip): this wave's atomics acknowledged
+    // (vmcnt(0)) -> workgroup barrier -> device-scope ticket -> the last workgroup reads the tile with agent-scope (sc1) loads, which go
+    // through to the memory side where the atomics were performed - no cache-wide fence.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // (also: every wave is past its last read of Ah)
+    int* const flag = reinterpret_cast<int*>(&Bs[0][0]);
+    if (tid == 0) {
+      const int per = (ncs + (int)gridDim.z - 1) / (int)gridDim.z, active = (ncs + per - 1) / per;       // splits with an empty slab range left at the top
+      const unsigned ticket = __hip_atomic_fetch_add(p.tickets + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = ticket == (unsigned)(active - 1);
+      if (ticket == (unsigned)(active - 1)) __hip_atomic_store(p.tickets + by, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // 252 threads = 12 float4 columns x 21 row groups; partial sums through Ah ([21][48][2] floats), then one thread per channel
+    const int q4 = tid % 12, rg = tid / 12;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (tid < 252 && n0 + q4 * 4 < p.N) {
+      const __amdgpu_buffer_rsrc_t srdO = make_srd(p.out, (unsigned)(((long)(p.M - 1) * p.ldc + p.N) * 4));
+      constexpr int RPT = (BM + 20) / 21;
+      float4 v[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int r = rg + 21 * k, m = m0 + r;
+        v[k] = (r < BM && m < p.M) ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srdO, (int)((unsigned)m * (unsigned)(p.ldc * 4) + (unsigned)((n0 + q4 * 4) * 4)), 0, 16))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        s0.x += v[k].x; s0.y += v[k].y; s0.z += v[k].z; s0.w += v[k].w;
+        s1.x = fmaf(v[k].x, v[k].x, s1.x); s1.y = fmaf(v[k].y, v[k].y, s1.y); s1.z = fmaf(v[k].z, v[k].z, s1.z); s1.w = fmaf(v[k].w, v[k].w, s1.w);
+      }
+    }
+    __syncthreads();                                                   // the flag has been read by every thread
+    if (tid < 252) {
+      *reinterpret_cast<float4*>(&Ah[(rg * 48 + q4 * 4) * 2]) = make_float4(s0.x, s1.x, s0.y, s1.y);
+      *reinterpret_cast<float4*>(&Ah[(rg * 48 + q4 * 4) * 2 + 4]) = make_float4(s0.z, s1.z, s0.w, s1.w);
+    }
+    __syncthreads();
+    if (tid < 48 && n0 + tid < p.N) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int r = 0; r < 21; ++r) { a += Ah[(r * 48 + tid) * 2]; b += Ah[(r * 48 + tid) * 2 + 1]; }
+      atomicAdd(p.stat0 + n0 + tid, (double)a);
+      atomicAdd(p.stat1 + n0 + tid, (double)b);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,7 +1060,9 @@ static int launch_conv_fwd_impl(const FwdArgs& a_in, bool b_kstrided, Epilogue e
     RDM_CENSUS("conv3x3_halo_kernel/%s/px%d/hl%d/%s", halo_dgrad ? "dgrad" : "fwd", bm, small ? std::max(hl, 3) : std::max(hl, 5), epi_name(epi));
     if (a.a_sum != nullptr) {                     // RAW BatchNorm prologue: the 128-pixel forward tiles of the few-pixel blocks only
       RDM_CHECK_ARG(small && halo_fwd && a.C <= RAWBN_MAX_C && (epi == EPI_STORE || epi == EPI_ATOMIC), "conv3x3: the raw BatchNorm prologue is built for the 128-pixel forward tiles, C <= %d", RAWBN_MAX_C);
-      RDM_CENSUS("conv3x3_halo_kernel/fwd/px128/hl%d/%s/rawbn", std::max(hl, 3), epi_name(epi));
+      RDM_CHECK_ARG(a.tickets == nullptr || (epi == EPI_ATOMIC && a.stat0 && a.stat1 && a.N <= 48 && a.ldc % 4 == 0 && ((uintptr_t)a.out & 15) == 0),
+                    "conv3x3: in-launch statistics belong to the accumulating raw-BatchNorm form with <= 48 outputs, rows 16-byte aligned");
+      RDM_CENSUS("conv3x3_halo_kernel/fwd/px128/hl%d/%s/rawbn%s", std::max(hl, 3), epi_name(epi), a.tickets ? "/stats" : "");
       if (epi == EPI_STORE) { if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_STORE, 3, false, 2, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_STORE, 4, false, 2, true>), grid, dim3(256), 0, s, a); }
       else { if (hl <= 3) hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_ATOMIC, 3, false, 2, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv3x3_halo_kernel<EPI_ATOMIC, 4, false, 2, true>), grid, dim3(256), 0, s, a); }
       RDM_LAUNCH_OK();

@@ -167,7 +167,7 @@ struct NetImpl {
   BlockGeom bg[4];
   int M1;
   // workspace offsets
-  size_t patches, e1, argmax, blk[4], blkstat[4], stats_begin, stats_end, stem_wp, logits, w2pad;
+  size_t patches, e1, argmax, blk[4], blkstat[4], stats_begin, stats_end, stem_wp, logits, w2pad, tickets;
   std::vector<LayerWs> lws[4];
   size_t transP[3], transBn[3];
   // backward scratch
@@ -234,6 +234,7 @@ struct NetImpl {
   int opt_defer_norm1 = 1;     // RDM_NET_OPT_DEFER_NORM1: see k_bn_bwd_defer (elementwise.hip); blocks on the xs 1x1 dgrad only
   int opt_gemm_bf16 = 0;       // RDM_NET_OPT_GEMM_BF16: the launches routed to xsplit.hip round their operands to bf16 (one MFMA per product) - mixed-precision arithmetic
   int xs_np() const { return (opt_gemm_bf16 & 2) ? 1 : 3; }      // value bits: 1 = the forward GEMMs, 2 = the gradient GEMMs (3 = both)
+  int opt_fuse_stats3 = 1;     // RDM_NET_OPT_FUSE_STATS3: the K-split 3x3 conv of the few-pixel blocks takes the channel statistics of its output in the same launch
   int opt_split_fwd = 0;       // RDM_NET_OPT_SPLIT_FWD: conv1 of the many-pixel blocks on the three-way-split bf16x6 forward kernel
   int xf_min_pixels = XF_LAYOUT_MIN_PIXELS;
   bool xf_block(int b) const { return opt_split_fwd && !opt_det && bg[b].M >= xf_min_pixels; }
@@ -324,6 +325,7 @@ struct NetImpl {
     // all f64 statistics live in one region so a single memset zeroes them per forward
     stats_begin = a.take<double>(0);
     for (int b = 0; b < 4; ++b) blkstat[b] = a.take<double>(2 * (size_t)bg[b].ctot);
+    tickets = a.take<double>(64);                                     // 128 unsigned counters (conv3x3_halo_kernel's in-launch statistics): zeroed with the statistics, left zero by every launch
     for (int b = 0; b < 4; ++b) {
       lws[b].resize(kBlocks[b].layers);
       for (auto& L : lws[b]) L.statY = a.take<double>(2 * (size_t)bg[b].cb);
@@ -579,6 +581,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
       c.a_scale = nullptr; c.a_shift = nullptr;
       c.a_sum = sty; c.a_sq = sty + g.cb; c.a_gamma = F(T, L.bn2.w); c.a_beta = F(T, L.bn2.b); c.a_count = (double)g.M;
       c.accumulate = 1;                                                 // the slice was zeroed with the whole block at its start
+      if (n.opt_fuse_stats3 && cdiv(g.M, 128) <= 128) c.tickets = at<unsigned>(ws, n.tickets);      // the last K split of a pixel tile takes the tile's statistics
     }
     if (n.wino_fwd[b] && !n.opt_no_wino) {
       // Winograd F(2x2, 3x3): the ordered reduction of the split partials also takes the channel statistics (no zero fill, no separate pass)
@@ -592,7 +595,7 @@ int forward_block(NetImpl& n, int b, void* ws, void* const* T, int training, hip
     } else {
       const bool fuse2 = training && fuse_stats(g.M, GROWTH);
       if ((rc = launch_conv_fwd(c, false, fuse2 ? EPI_STORE_STATS : EPI_STORE, s)) < 0) return rc;
-      if (training && !fuse2 && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
+      if (training && !fuse2 && c.tickets == nullptr && (rc = launch_colstats(blk + cin, g.ctot, g.M, GROWTH, bst + cin, bst + g.ctot + cin, s))) return rc;
     }
     if (pipelined) RDM_HIP_OK(hipEventRecord(n.ev_fs[i & 1], s));     // layer i's output channels + their statistics are final
   }
@@ -931,6 +934,7 @@ int rdm_net_set_option(rdm_net* net, int32_t option, int32_t value) {
   else if (option == RDM_NET_OPT_GEMM_BF16) n->opt_gemm_bf16 = value == 1 ? 3 : value == 2 ? 1 : value == 3 ? 2 : 0;      // 1 = both, 2 = forward GEMMs only, 3 = gradient GEMMs only
   else if (option == RDM_NET_OPT_SPLIT_ROWS) n->opt_split_rows = value != 0;
   else if (option == RDM_NET_OPT_WINO_X6) n->opt_wino_x6 = value != 0;
+  else if (option == RDM_NET_OPT_FUSE_STATS3) n->opt_fuse_stats3 = value != 0;
   else if (option == RDM_NET_OPT_SPLIT_FWD) {
     n->opt_split_fwd = value != 0;
 #ifdef RDM_DEV_VARIANTS

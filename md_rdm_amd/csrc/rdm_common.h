@@ -106,6 +106,9 @@ struct FwdArgs {            // C[m][n] = sum_{tap,c} f(A[pix(m,tap)][c]) * Wt[ta
   int a_split;                                // xs 1x1 dgrad, three-product form: A (the gradient operand) is SPLIT ROWS (xsplit_dev.h)
   // xs 1x1 dgrad with the gate epilogue only: `out` is the block gradient and receives  out += x_scale * (gated dz)  (deferred norm1 backward)
   int acc_scaled;
+  // conv3x3_halo_kernel, raw-BatchNorm form with the accumulating (K-split) epilogue only: one zeroed counter per pixel tile.  When set, the LAST
+  // split of a tile to arrive takes the channel statistics (stat0 / stat1) of the finished tile in the same launch (no separate reduction pass).
+  unsigned* tickets;
 };
 constexpr int RAWBN_MAX_C = 768;
 

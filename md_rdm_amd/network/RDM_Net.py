@@ -320,6 +320,7 @@ class DepthEstimationNet(BaseModel):
         self.forward_split = True    # conv1 of dense_e2 / dense_e3 on the three-way-split bf16x6 kernel (RDM_NET_OPT_SPLIT_FWD: float32-equivalent accuracy, measured
                                    # 3-9e-7 of the result's maximum against float64 - the f32 MFMA kernel's own level); False: exact-f32 MFMA
         self.prepack = True          # RDM_NET_OPT_PREPACK: the split kernels' weight images are formed for all layers once per step on the side stream (off the dependent chains)
+        self.fuse_stats3 = True      # RDM_NET_OPT_FUSE_STATS3: the K-split 3x3 conv of the few-pixel blocks takes its output's channel statistics in the same launch (training forward)
         self.wino_x6 = False         # RDM_NET_OPT_WINO_X6: conv2 (3x3) of dense_e2 / dense_e3 forward as Winograd on three-way-split bf16 MFMAs (float32-equivalent; with forward_split).
                                      # Correct (2e-6 of the maximum vs float64) but NOT faster than the f32 MFMA kernel at these sizes (7.1 vs 6.7 ms per step): the kernel is bound by
                                      # its producers and the per-workgroup prologue / epilogue of the deep K split, not by the matrix pipe (profiles/r05_wino_x6_ablation.txt)
@@ -417,7 +418,7 @@ class DepthEstimationNet(BaseModel):
             self.flatten_parameters()
 
     def _plan(self, B, H, W):
-        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1), bool(self.prepack), bool(self.split_rows), bool(self.wino_x6))
+        key = (B, H, W, bool(self.deterministic), self.backward_precision, bool(self.forward_split), int(self.gemm_bf16), bool(self.defer_norm1), bool(self.prepack), bool(self.split_rows), bool(self.wino_x6), bool(self.fuse_stats3))
         if self.backward_precision not in ("f32", "bf16x3"):
             raise ValueError("backward_precision must be 'f32' or 'bf16x3'")
         if key not in self._plans:
@@ -434,6 +435,7 @@ class DepthEstimationNet(BaseModel):
             _lib.check(L.rdm_net_set_option(h, 9, 1 if self.defer_norm1 else 0))                         # RDM_NET_OPT_DEFER_NORM1
             _lib.check(L.rdm_net_set_option(h, 11, 1 if self.split_rows else 0))                         # RDM_NET_OPT_SPLIT_ROWS
             _lib.check(L.rdm_net_set_option(h, 12, 1 if self.wino_x6 else 0))                            # RDM_NET_OPT_WINO_X6
+            _lib.check(L.rdm_net_set_option(h, 13, 1 if self.fuse_stats3 else 0))                        # RDM_NET_OPT_FUSE_STATS3
             _lib.check(L.rdm_net_set_option(h, 8, int(self.gemm_bf16)))                          # RDM_NET_OPT_GEMM_BF16
             oh, ow = C.c_int32(), C.c_int32()
             _lib.check(L.rdm_net_output_hw(h, C.byref(oh), C.byref(ow)))

@@ -585,3 +585,38 @@ def test_deferred_norm1_backward_gives_the_same_gradients(dev):
         dist = sum(float((a[n] - c[n]).pow(2).sum()) for n in names) ** 0.5 / norm
         print(f"[deferred norm1] {prefix}: two runs of one mode {floor:.2e} of the gradient norm, the two modes {dist:.2e}")
         assert dist <= 3.0 * floor + 2e-3, (prefix, floor, dist)
+
+
+def test_in_launch_statistics_of_the_few_pixel_3x3_match_the_separate_pass(dev):
+    """RDM_NET_OPT_FUSE_STATS3 (default on): in the training forward of dense_e4 / d_1 the K-split 3x3 convolution of a layer (torchvision
+    _DenseLayer.conv2, RDM_Net.py:144,530) takes the channel statistics of its 48 outputs itself - the last split of a pixel tile to arrive reduces the
+    finished tile - instead of a column-reduction launch.  Those sums feed norm1 of every later layer of the block: after one training forward from the
+    same state the running statistics of every BatchNorm of the two blocks agree with the separate pass to 1e-4 of their maximum (a tile counted
+    twice or missed would move a mean by 1 / 36 at dense_e4), the logits to 1e-3, and the census shows which form ran."""
+    from md_rdm_amd import filler, _lib
+    from md_rdm_amd.network.RDM_Net import DepthEstimationNet
+    x, _ = filler.synthetic_batch(4, 228, 304, seed=filler.MARGIN_SEEDS["train228x304"])
+    xg = torch.from_numpy(x).to(dev)
+    got = []
+    for fuse in (False, True):
+        m = DepthEstimationNet()
+        filler.fill_state_dict(m.state_dict())
+        m = m.to(dev).train()
+        m.fuse_stats3 = fuse
+        L = _lib.lib()
+        L.rdm_census_enable(1)
+        before = _lib.census()
+        with torch.no_grad():
+            m(xg)
+        torch.cuda.synchronize()
+        after = _lib.census()
+        L.rdm_census_enable(0)
+        names = [k for k in after if after[k] > before.get(k, 0) and k.startswith("conv3x3_halo_kernel/fwd/px128") and "rawbn" in k]
+        assert names and all(k.endswith("/stats") == fuse for k in names), (fuse, names)
+        bufs = {n: b.detach().double().cpu().clone() for n, b in m.named_buffers() if ("dense_e4" in n or n.startswith("d_1.")) and ("running_mean" in n or "running_var" in n)}
+        got.append((bufs, m.debug_buffer("logits").double().cpu().clone()))
+    (a, la), (b, lb) = got
+    assert len(a) >= 2 * (36 + 24) * 2 - 8
+    for n in a:
+        assert float((a[n] - b[n]).abs().max()) <= 1e-4 * float(a[n].abs().max()) + 1e-7, n
+    assert float((la - lb).abs().max()) <= 1e-3 * float(la.abs().max())
