@@ -6,7 +6,7 @@ TAG=${1:-rNN}
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err      # the driver's invocation
 cp bench_detail.json $O/bench_detail.json          # the full record of THAT run (the profiling runs below overwrite bench_detail.json)
 echo bench done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o train -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline --no-extra-configs > $O/trace.log 2>&1
