@@ -109,6 +109,15 @@ int rdm_conv2d_fwd_bnsums(const rdm_conv_desc* d, const float* x, const float* w
                           const float* bn_gamma, const float* bn_beta, float* y, double* stat_sum, double* stat_sq, int32_t split_k,
                           rdm_stream_t stream);
 
+/* The 3x3 / pad 1 convolution of a few-pixel dense layer as rdm_net_forward runs it in training (round 5): raw-BatchNorm prologue as above, the result
+ * ADDED into y (the caller zeroes the 48-channel slice once per block; any K split, f32 atomics), and the channel statistics of the FINISHED y taken
+ * in the same launch - tile_tickets: one zeroed uint32 per 128-pixel tile (ceil(pixels / 128)), left zero; the last K split of a tile to arrive
+ * reduces the tile into stat_sum / stat_sq (f64, pre-zeroed, +=).  RDM_ERR_BAD_ARGUMENT outside the raw form's limits (<= 8 192 pixels, width <= 63,
+ * in_c <= 768, out_c <= 48, y rows 16-byte aligned). */
+int rdm_conv3x3_fwd_bnsums_acc(const rdm_conv_desc* d, const float* x, const float* w_packed, const double* bn_sum, const double* bn_sumsq, double bn_count,
+                               const float* bn_gamma, const float* bn_beta, float* y, double* stat_sum, double* stat_sq, uint32_t* tile_tickets,
+                               int32_t split_k, rdm_stream_t stream);
+
 /* The same three operators with the K-split chosen by the caller: split_k = 0 keeps the launcher's own choice (what the plain entry
  * points do), 1 forbids splitting (no atomics: one workgroup owns every output element, bit-reproducible), n > 1 asks for n partial
  * sums added with f32 atomics into a zeroed output (the launcher clamps n to the number of K slabs; statistics / bias epilogues

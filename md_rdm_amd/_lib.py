@@ -38,6 +38,7 @@ _SIGNATURES = {
     "rdm_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "rdm_conv2d_fwd_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_fwd_bnsums": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
+    "rdm_conv3x3_fwd_bnsums_acc": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_dgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_wgrad_ex": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
     "rdm_conv2d_wgrad_x3": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i32, i32, vp]),

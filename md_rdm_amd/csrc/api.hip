@@ -155,6 +155,27 @@ int rdm_conv2d_fwd_bnsums(const rdm_conv_desc* d, const float* x, const float* w
   return rc < 0 ? rc : RDM_OK;
 }
 
+int rdm_conv3x3_fwd_bnsums_acc(const rdm_conv_desc* d, const float* x, const float* w, const double* bn_sum, const double* bn_sumsq, double bn_count,
+                               const float* bn_gamma, const float* bn_beta, float* y, double* stat_sum, double* stat_sq, uint32_t* tile_tickets, int32_t split_k,
+                               rdm_stream_t stream) {
+  RDM_CHECK_ARG(split_k >= 0 && split_k <= 128, "conv3x3_fwd_bnsums_acc: split_k (%d) must be 0 (auto) .. 128", (int)split_k);
+  ConvGeom g;
+  int rc = geom_from_desc(d, &g);
+  if (rc) return rc;
+  RDM_CHECK_ARG(x && w && y && bn_sum && bn_sumsq && bn_gamma && bn_beta && bn_count >= 1 && stat_sum && stat_sq && tile_tickets, "conv3x3_fwd_bnsums_acc: NULL operand");
+  RDM_CHECK_ARG(d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->out_c <= 48 && ((uintptr_t)tile_tickets & 3) == 0,
+                "conv3x3_fwd_bnsums_acc: a 3x3 / stride 1 / pad 1 convolution with <= 48 outputs");
+  FwdArgs a{};
+  a.g = g; a.A = x; a.lda = d->in_ld; a.C = d->in_c;
+  a.a_sum = bn_sum; a.a_sq = bn_sumsq; a.a_gamma = bn_gamma; a.a_beta = bn_beta; a.a_count = bn_count;
+  a.Wt = w; a.wtap = (long)d->out_c * d->in_c; a.ldw = d->in_c;
+  a.out = y; a.ldc = d->out_ld; a.M = g.B * g.Ho * g.Wo; a.N = d->out_c;
+  a.stat0 = stat_sum; a.stat1 = stat_sq;
+  a.split_k = split_k; a.accumulate = 1; a.tickets = tile_tickets;
+  rc = launch_conv_fwd(a, false, EPI_STORE, stream);
+  return rc < 0 ? rc : RDM_OK;
+}
+
 int rdm_conv2d_dgrad(const rdm_conv_desc* d, const float* dy, const float* w, float* dx, int32_t dx_ld, const float* mask_x, int32_t mask_ld,
                      const float* mask_scale, const float* mask_shift, double* stat_a, double* stat_b, rdm_stream_t stream) {
   return rdm_conv2d_dgrad_ex(d, dy, w, dx, dx_ld, mask_x, mask_ld, mask_scale, mask_shift, stat_a, stat_b, 0, stream);

@@ -423,8 +423,27 @@ def test_conv_fwd_with_raw_batchnorm_sums(case):
     y2 = torch.empty(M, Cout, device=dev)
     check(L.rdm_conv2d_fwd_ex(C.byref(d), ptr(xg), ptr(wg), None, ptr(coef[0]), ptr(coef[1]), ptr(y2), None, None, 1, stream()))
     assert torch.equal(outs[1], y2)
+    if kh == 3:
+        # the plan's form (round 5): added into a zeroed slice of a wider buffer, the statistics of the finished tile taken by the last K split to arrive
+        ldo = 96
+        for split in (0, 1, 5):
+            yb = torch.zeros(M, ldo, device=dev)
+            s0 = torch.zeros(Cout, dtype=torch.float64, device=dev)
+            s1 = torch.zeros_like(s0)
+            tickets = torch.zeros((M + 127) // 128, dtype=torch.int32, device=dev)
+            da = ConvDesc(B, H, W, Cin, ld, Cout, ldo, kh, kw, 1, 1, 1, 1)
+            for rep in range(2):                                          # twice into the same tickets: they are left zero
+                yb.zero_(); s0.zero_(); s1.zero_()
+                check(L.rdm_conv3x3_fwd_bnsums_acc(C.byref(da), ptr(xg), ptr(wg), ptr(ssum), ptr(ssq), float(M), ptr(gg), ptr(bg), C.c_void_p(yb.data_ptr() + 48 * 4), ptr(s0), ptr(s1), ptr(tickets), split, stream()))
+                torch.cuda.synchronize()
+                assert int(tickets.abs().max()) == 0
+                got = yb[:, 48:48 + Cout].cpu().double()
+                assert rel(got, want) < TOL and float(yb[:, :48].abs().max()) == 0.0, (split, rep)
+                # the statistics are those of the STORED values (every tile exactly once), to float32 summation accuracy
+                assert rel(s0.cpu(), got.sum(0)) < 2e-6 * M ** 0.5 and rel(s1.cpu(), (got ** 2).sum(0)) < 1e-5, (split, rep)
     cen = _lib.census()
     assert any(k.endswith("/rawbn") for k in cen), sorted(cen)
+    assert kh != 3 or any(k.endswith("/rawbn/stats") for k in cen), sorted(cen)
     _RAN.add(("rawbn",) + case)
 
 
