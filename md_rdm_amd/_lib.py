@@ -221,9 +221,12 @@ def ptr(t):
 
 
 def stream():
-    """The caller's current HIP stream.  Through the raw query: ``torch.cuda.current_stream()`` builds a Stream object and asks the runtime for the device
-    count on the way (hipGetDeviceCount, ~20 us per call on this stack - ~100 C-ABI calls per training step sit in the host-paced phases between the
-    native forward and backward, where the GPU waits for the host; tools/host_lead.py)."""
+    """The caller's current HIP stream.  Through the raw query where this torch has it: ``torch.cuda.current_stream()`` builds a Stream object and asks the
+    runtime for the device count on the way (hipGetDeviceCount, ~20 us per call on this stack; ~100 C-ABI calls per training step; the host is two steps
+    ahead of the GPU in steady state, so this only shortens the first step after a synchronisation - tools/host_pace.py)."""
     import torch
 
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    raw, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+    if raw is not None and dev is not None:
+        return C.c_void_p(raw(dev()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
